@@ -1,0 +1,181 @@
+/*
+ * slim_gpu.h -- the rest of libslim.so's C ABI:
+ *   (1) slim_csr_t, the concrete object behind slim_t handles;
+ *   (2) the Py_* entry points the reference's Python wrapper resolves by name
+ *       (they are declared in no reference header; bodies in
+ *       /root/reference/src/libslim/pyapi.c);
+ *   (3) SLIMGPU_* engine extensions: matrices resident in HBM, column-sharded
+ *       solves for one-process-per-GPU jobs, and the counters bench.py reports.
+ * Plain C types only: pointers and sizes, no torch/HIP types in any signature
+ * (streams and device buffers are passed as void* / typed raw pointers).
+ */
+#ifndef SLIM_AMD_SLIM_GPU_H_
+#define SLIM_AMD_SLIM_GPU_H_
+
+#include "slim.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------
+ * (1) slim_csr_t: field-for-field the layout of GKlib's gk_csr_t (GKlib is an
+ * empty submodule in the reference; layout recalled from upstream
+ * gk_struct.h and consistent with every use in the reference's src/libslim sources), so that
+ * callers compiled against GKlib can keep dereferencing model handles
+ * (src/programs/slim_learn.c:83, slim_mselect.c:189-195, slim_predict.c:34).
+ * Every array is malloc'd by the library or NULL.  A trained model carries both
+ * views: col* (column iC = regressors of item iC; read by warm start,
+ * src/libslim/estimate.c:455-458) and row* (read by prediction,
+ * src/libslim/predict.c:46-57).
+ * ------------------------------------------------------------------------- */
+typedef struct slim_csr_t {
+  int32_t nrows, ncols;
+  ssize_t *rowptr, *colptr;
+  int32_t *rowind, *colind;
+  int32_t *rowids, *colids;
+  int32_t *rlabels, *clabels;
+  int32_t *rmap, *cmap;
+  float *rowval, *colval;
+  float *rnorms, *cnorms;
+  float *rsums, *csums;
+  float *rsizes, *csizes;
+  float *rvols, *cvols;
+  float *rwgts, *cwgts;
+} slim_csr_t;
+
+/* ---------------------------------------------------------------------------
+ * (2) Python-facing entry points.  All return SLIM_OK / SLIM_ERROR*.
+ * ------------------------------------------------------------------------- */
+
+/* Deep-copy a CSR matrix into a library-owned handle (ncols = max id + 1).
+ * Replaces Py_csr_wrapper, src/libslim/pyapi.c:22-38. */
+int32_t Py_csr_wrapper(int32_t nrows, ssize_t *rowptr, int32_t *rowind,
+                       float *rowval, slim_t **matrix_out);
+/* Text CSR save/load of a handle's row view (pyapi.c:47-64). */
+int32_t Py_csr_save(slim_t *mathandle, char *fname);
+int32_t Py_csr_load(slim_t **mathandle, char *fname);
+/* Release a handle (pyapi.c:72-76). */
+int32_t Py_csr_free(slim_t *mathandle);
+/* nnz of the row view, narrowed to int32 as in the reference (pyapi.c:85-89). */
+int32_t Py_csr_stat(slim_t *mathandle, int32_t *nnz);
+/* Copy the row view out as int32 indptr/indices + float data (pyapi.c:101-123). */
+int32_t Py_csr_export(slim_t *mathandle, int32_t *indptr, int32_t *indices,
+                      float *data);
+/* SLIM_Learn on a wrapped training matrix, no warm start (pyapi.c:134-199). */
+int32_t Py_SLIM_Learn(slim_t *trnhandle, int32_t *ioptions, double *doptions,
+                      slim_t **model_out);
+/* l1 x l2 grid with warm start from the previous cell and HR/ARHR evaluation;
+ * the 8 outputs are the best-HR and best-ARHR cells (pyapi.c:214-412). */
+int32_t Py_SLIM_Mselect(slim_t *trnhandle, slim_t *tsthandle, int32_t *ioptions,
+                        double *doptions, double *arrayl1, double *arrayl2,
+                        int32_t nl1, int32_t nl2, double *bestl1HR,
+                        double *bestl2HR, double *bestHRHR, double *bestARHR,
+                        double *bestl1AR, double *bestl2AR, double *bestHRAR,
+                        double *bestARAR);
+/* Single-profile top-N (pyapi.c:414-469). Return the list length or SLIM_ERROR. */
+int32_t Py_SLIM_GetTopN(slim_t *model, int32_t nratings, int32_t *itemids,
+                        float *ratings, int32_t nrcmds, int32_t *rids,
+                        float *rscores, int32_t dbglvl);
+int32_t Py_SLIM_GetTopN_1vsk(slim_t *model, int32_t nratings, int32_t *itemids,
+                             float *ratings, int32_t nrcmds, int32_t *rids,
+                             float *rscores, int32_t nnegs, int32_t *negitems,
+                             int32_t dbglvl);
+/* Top-N for every row of trnhandle; output[u*nrcmds + r] (pyapi.c:483-563). */
+int32_t Py_SLIM_Predict(int32_t nrcmds, slim_t *slimhandle, slim_t *trnhandle,
+                        int32_t *output, float *scores);
+int32_t Py_SLIM_Predict_1vsk(int32_t nrcmds, int32_t nnegs, slim_t *slimhandle,
+                             slim_t *trnhandle, int32_t *negitems,
+                             int32_t *output, float *scores);
+
+/* ---------------------------------------------------------------------------
+ * (3) Engine extensions.
+ * ------------------------------------------------------------------------- */
+
+/* Extra option slots (reference leaves 11..39 unused, include/slim.h:215-230).
+ * -1 selects the default, like every other slot. */
+enum {
+  SLIM_OPTION_GPU_COLBEGIN = 11, /* first item column solved by this call [0]  */
+  SLIM_OPTION_GPU_COLEND = 12,   /* one past the last column [ncols]; columns
+                                    outside the range come back empty          */
+  SLIM_OPTION_GPU_SEED = 13,     /* seed of the visiting permutation [1]       */
+  SLIM_OPTION_GPU_DEVICE = 14,   /* HIP device ordinal [current device]        */
+  SLIM_OPTION_GPU_KERNEL = 15    /* slimgpu_kernel_et [SLIMGPU_KERNEL_AUTO]    */
+};
+
+typedef enum {
+  SLIMGPU_KERNEL_AUTO = 0,
+  SLIMGPU_KERNEL_WAVE_LDS = 1, /* one wavefront per item, work vectors in LDS  */
+  SLIMGPU_KERNEL_WAVE_HBM = 2  /* one wavefront per item, work vectors in HBM  */
+} slimgpu_kernel_et;
+
+/* A training matrix staged in HBM: CSR as given + the column view (CSC, rows
+ * ascending inside each column) + column norms, i.e. the device form of
+ * CreateTrainingMatrix (src/libslim/setup.c:109-135). */
+typedef struct slimgpu_matrix slimgpu_matrix_t;
+
+/* Stage a host CSR (H2D once) and build the column view on the device. */
+slimgpu_matrix_t *SLIMGPU_MatrixFromHost(int32_t nrows, const ssize_t *rowptr,
+                                         const int32_t *rowind,
+                                         const float *rowval,
+                                         int32_t *ioptions, int32_t *r_status);
+/* Adopt CSR arrays that already live in HBM (int64 rowptr[nrows+1], int32
+ * rowind[nnz], float rowval[nnz] or NULL); they are borrowed and must outlive
+ * the handle.  ncols <= 0: computed as max id + 1.  Work queued on other
+ * streams that produces these arrays must be complete before the call. */
+slimgpu_matrix_t *SLIMGPU_MatrixFromDevice(int32_t nrows, int32_t ncols,
+                                           const int64_t *d_rowptr,
+                                           const int32_t *d_rowind,
+                                           const float *d_rowval,
+                                           int32_t *ioptions, int32_t *r_status);
+void SLIMGPU_MatrixFree(slimgpu_matrix_t **mat);
+int32_t SLIMGPU_MatrixInfo(const slimgpu_matrix_t *mat, int32_t *nrows,
+                           int32_t *ncols, int64_t *nnz);
+/* Copy the device column view back (any pointer may be NULL): tests compare it
+ * with the oracle's transpose. */
+int32_t SLIMGPU_MatrixGetColumnView(const slimgpu_matrix_t *mat, int64_t *colptr,
+                                    int32_t *colind, float *colval,
+                                    float *cnorms);
+
+/* The estimate step of SLIM_Learn (EstimateModelCD + SaveModel,
+ * src/libslim/estimate.c:328-593) on a staged matrix.  Same options, imodel and
+ * result conventions as SLIM_Learn; can be called repeatedly on one matrix
+ * (model-selection grids keep R resident). */
+slim_t *SLIMGPU_Learn(slimgpu_matrix_t *mat, int32_t *ioptions,
+                      double *doptions, slim_t *imodel, int32_t *r_status);
+
+/* Counters of the most recent solve on this thread. */
+typedef struct slimgpu_stats_t {
+  int32_t ncols_solved;
+  int32_t kernel;          /* slimgpu_kernel_et actually used                 */
+  int32_t nwaves;          /* persistent wavefronts launched                  */
+  int32_t lds_bytes;       /* dynamic LDS per wavefront (0 for the HBM kernel) */
+  double setup_ms;         /* host->HBM staging + column view (FromHost only) */
+  double kernel_ms;        /* solver kernel, HIP events on the engine stream  */
+  double gather_ms;        /* D2H of W + host assembly of the model           */
+  double total_ms;         /* wall time of the call                           */
+  int64_t G, D, U, nnzW;   /* sums of the per-column traffic terms below      */
+  int64_t sweeps;          /* total CD sweeps                                 */
+  int64_t visits;          /* total coordinate visits                         */
+  double alg_bytes;        /* 8G + 12D + 4U + 8 nnzW (4G + 8D + 4U + 8 nnzW
+                              for a binary matrix): SURVEY.md 8(d)            */
+  double error, objval;    /* sum of 1/2||r||^2 and of the objective          */
+} slimgpu_stats_t;
+int32_t SLIMGPU_LastStats(slimgpu_stats_t *out);
+
+/* Per-column counters of the most recent solve (arrays of ncols entries; any
+ * may be NULL): active-set size, sweeps (wspace->niters), convergence flag,
+ * G = sum over the column's users of nnz(row u), D = sum over sweeps and active
+ * columns of nnz(col i), U = same restricted to visits that changed x. */
+int32_t SLIMGPU_LastColumnStats(int32_t ncols, int32_t *nacols, int32_t *sweeps,
+                                int32_t *conv, int64_t *G, int64_t *D,
+                                int64_t *U);
+
+int32_t SLIMGPU_DeviceCount(void);
+/* Human-readable description of the last failure on this thread ("" if none). */
+const char *SLIMGPU_LastError(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLIM_AMD_SLIM_GPU_H_ */

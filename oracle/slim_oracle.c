@@ -1,0 +1,811 @@
+/*
+ * slim_oracle.c -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference's
+ * SLIM coordinate-descent training path (and of the top-N / HR evaluation that
+ * defines the parity metric).  Nothing in the shipped product (slim_amd/,
+ * libslim.so) may include, link, import or call this file; only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * Provenance.  Own code, written from the behaviour of the reference at
+ * /root/reference (KarypisLab/SLIM); each function cites the reference
+ * file:line it restates.  The reference itself is UNBUILDABLE in this image:
+ * src/libslim/slimlib.h:14 includes <GKlib.h> and lib/GKlib is an empty,
+ * un-vendored submodule (.gitmodules:1-3).  GKlib (github.com/KarypisLab/GKlib,
+ * version unpinned by the reference) owns three pieces of arithmetic on the
+ * path; they are restated here from their published algorithm and from the
+ * reference's call sites:
+ *   gk_csr_CreateIndex   counting-sort transpose, rows ascending inside each
+ *                        column           (call sites setup.c:128, estimate.c:591)
+ *   gk_csr_ComputeNorms  cnorm = (float)sqrt(fp32 sum of val^2) (setup.c:130)
+ *   gk_fkvsortd          descending sort by float key; tie order undefined
+ *                        upstream (unstable quicksort) -- stable here
+ *                                                         (predict.c:60,123)
+ *
+ * Pinning (see tests/test_oracle_pins.py): the reference ships no tests; its
+ * only recorded outputs are python-package/UserGuide.ipynb:275-277 (Automotive
+ * 9x9 model selection: best-HR and best-AR lines), which this oracle
+ * reproduces exactly, plus the SURVEY.md 8(c) probe values.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -fopenmp -shared).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_EPS 1e-7 /* def.h:14 EPSILON */
+
+/* float key + index pair: GKlib gk_fkv_t {float key; ssize_t val;} */
+typedef struct {
+  float key;
+  int64_t val;
+} fkv_t;
+
+/* ------------------------------------------------------------------------ */
+/* visiting-order generators                                                 */
+/* ------------------------------------------------------------------------ */
+
+/* cd.c:76-86 ShuffleList: "swap element i with a random index in [0,n)",
+ * libc rand(), never seeded by the reference.                               */
+static void shuffle_glibc(fkv_t *list, int32_t n) {
+  for (int32_t i = 0; i < n; i++) {
+    fkv_t t = list[i];
+    int32_t j = rand() % n;
+    list[i] = list[j];
+    list[j] = t;
+  }
+}
+
+/* thread-local xorshift variant of the same swap shuffle (the
+ * "thread-local PRNG" CPU-baseline mode; glibc rand() serialises threads).   */
+static inline uint32_t xs32(uint32_t *s) {
+  uint32_t x = *s;
+  x ^= x << 13;
+  x ^= x >> 17;
+  x ^= x << 5;
+  return *s = x;
+}
+static void shuffle_local(fkv_t *list, int32_t n, uint32_t *state) {
+  for (int32_t i = 0; i < n; i++) {
+    fkv_t t = list[i];
+    int32_t j = (int32_t)(xs32(state) % (uint32_t)n);
+    list[i] = list[j];
+    list[j] = t;
+  }
+}
+
+/* Stateless keyed permutation of [0,n): the visiting order the HIP engine
+ * uses (slim_amd/csrc/cd_perm.h is the device twin; both are integer-exact,
+ * so engine and oracle can walk identical orders).  A bijection on b =
+ * ceil(log2 n) bits (odd multiply, add, xorshift-right are each invertible
+ * mod 2^b) followed by cycle walking into [0,n).                             */
+uint32_t oracle_perm_key(uint32_t seed, uint32_t item, uint32_t sweep) {
+  uint32_t h = seed * 0x9E3779B1u + 0x7F4A7C15u;
+  h ^= item + 0x85EBCA6Bu + (h << 6) + (h >> 2);
+  h *= 0xC2B2AE35u;
+  h ^= h >> 15;
+  h ^= sweep * 0x27D4EB2Fu + 0x165667B1u + (h << 6) + (h >> 2);
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+uint32_t oracle_perm_index(uint32_t p, uint32_t n, uint32_t key) {
+  if (n <= 1) return 0;
+  uint32_t b = 32u - (uint32_t)__builtin_clz(n - 1); /* ceil(log2 n), n>=2 */
+  uint32_t mask = (b >= 32) ? 0xFFFFFFFFu : ((1u << b) - 1u);
+  uint32_t s1 = (b + 1) / 2, s2 = (b + 2) / 3;
+  if (s2 == 0) s2 = 1;
+  uint32_t a1 = (key | 1u), c1 = key >> 7;
+  uint32_t a2 = ((key * 0x9E3779B1u) >> 3) | 1u, c2 = (key * 0x85EBCA6Bu) >> 11;
+  uint32_t a3 = ((key * 0xC2B2AE35u) >> 5) | 1u, c3 = key >> 17;
+  uint32_t x = p;
+  do {
+    x = (x * a1 + c1) & mask;
+    x ^= x >> s1;
+    x = (x * a2 + c2) & mask;
+    x ^= x >> s2;
+    x = (x * a3 + c3) & mask;
+    x ^= x >> s1;
+  } while (x >= n);
+  return x;
+}
+
+/* ------------------------------------------------------------------------ */
+/* setup: setup.c:109-135 CreateTrainingMatrix                                */
+/* ------------------------------------------------------------------------ */
+
+/* setup.c:117  ncols = gk_i32max(rowind)+1 */
+int32_t oracle_ncols(int64_t nnz, const int32_t *rowind) {
+  int32_t m = -1;
+  for (int64_t i = 0; i < nnz; i++)
+    if (rowind[i] > m) m = rowind[i];
+  return m + 1;
+}
+
+/* gk_csr_CreateIndex(GK_CSR_COL) [GKlib; call site setup.c:128]: counting-sort
+ * transpose.  Walking rows in ascending order makes every column's row ids
+ * ascending, which slim_csr_SortIndices (setup.c:19-94) then leaves untouched.
+ * val may be NULL (binary matrix, setup.c:122-126).                          */
+void oracle_transpose(int32_t nrows, int32_t ncols, const int64_t *ptr,
+                      const int32_t *ind, const float *val, int64_t *tptr,
+                      int32_t *tind, float *tval) {
+  memset(tptr, 0, sizeof(int64_t) * ((size_t)ncols + 1));
+  for (int64_t j = 0; j < ptr[nrows]; j++) tptr[ind[j] + 1]++;
+  for (int32_t c = 0; c < ncols; c++) tptr[c + 1] += tptr[c];
+  int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * ((size_t)ncols + 1));
+  memcpy(cur, tptr, sizeof(int64_t) * ((size_t)ncols + 1));
+  for (int32_t r = 0; r < nrows; r++)
+    for (int64_t j = ptr[r]; j < ptr[r + 1]; j++) {
+      int64_t d = cur[ind[j]]++;
+      tind[d] = r;
+      if (val && tval) tval[d] = val[j];
+    }
+  free(cur);
+}
+
+/* gk_csr_ComputeNorms(GK_CSR_COL) [GKlib; call site setup.c:130]:
+ * cnorms[i] = sqrt(sum val^2) with a float accumulator; sqrt(nnz) if binary. */
+void oracle_col_norms(int32_t ncols, const int64_t *colptr, const float *colval,
+                      float *cnorms) {
+  for (int32_t c = 0; c < ncols; c++) {
+    float s = 0.0f;
+    if (colval)
+      for (int64_t j = colptr[c]; j < colptr[c + 1]; j++)
+        s += colval[j] * colval[j];
+    else
+      s = (float)(colptr[c + 1] - colptr[c]);
+    cnorms[c] = (float)sqrt((double)s);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* cd.c:24-65 sparse axpy / dot on the column view                            */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  const int64_t *colptr;
+  const int32_t *colind;
+  const float *colval; /* NULL => binary */
+  const float *cnorms;
+} cview_t;
+
+/* cd.c:24-38 AddSpVec: skipped entirely when |xi| <= EPSILON */
+static inline int64_t add_spvec(const cview_t *A, int32_t i, double xi,
+                                double *yhat) {
+  if (xi > ORACLE_EPS || xi < -ORACLE_EPS) {
+    if (A->colval)
+      for (int64_t j = A->colptr[i]; j < A->colptr[i + 1]; j++)
+        yhat[A->colind[j]] += xi * A->colval[j];
+    else
+      for (int64_t j = A->colptr[i]; j < A->colptr[i + 1]; j++)
+        yhat[A->colind[j]] += xi;
+    return A->colptr[i + 1] - A->colptr[i];
+  }
+  return 0;
+}
+
+/* cd.c:51-65 SpVecInnerProduct */
+static inline double spvec_dot(const cview_t *A, int32_t i, const double *yhat) {
+  double res = 0.0;
+  if (A->colval)
+    for (int64_t j = A->colptr[i]; j < A->colptr[i + 1]; j++)
+      res += A->colval[j] * yhat[A->colind[j]];
+  else
+    for (int64_t j = A->colptr[i]; j < A->colptr[i + 1]; j++)
+      res += yhat[A->colind[j]];
+  return res;
+}
+
+/* ------------------------------------------------------------------------ */
+/* configuration                                                             */
+/* ------------------------------------------------------------------------ */
+enum { ORDER_GLIBC = 0, ORDER_PERM = 1, ORDER_LOCAL = 2, ORDER_NONE = 3 };
+enum { ATY_FULLSCAN = 0, ATY_GRAM = 1 };
+
+typedef struct {
+  double l1r, l2r, optTol; /* api.c:50-52 */
+  int32_t maxniters;       /* api.c:48 */
+  int32_t nthreads;        /* api.c:42 */
+  int32_t order;           /* ORDER_* */
+  uint32_t seed;           /* ORDER_PERM / ORDER_LOCAL */
+  int32_t aty;             /* ATY_* : estimate.c:412-421 vs Gram-column */
+  int32_t fp32;            /* 0: reference arithmetic (fp64 x/yhat, 3-pass)
+                              1: engine-style arithmetic (fp32 residual, fused) */
+} oracle_cfg_t;
+
+/* per-column counters (SURVEY 8(d) algorithmic-bytes terms) */
+typedef struct {
+  int32_t nacols; /* active-set size */
+  int32_t sweeps; /* wspace->niters, cd.c:140 */
+  int32_t conv;   /* rstatus, cd.c:136 */
+  int32_t nnzw;   /* kept entries */
+  int64_t G;      /* sum over users of col of nnz(row u) */
+  int64_t D;      /* sum over sweeps, active cols of nnz(col i) */
+  int64_t U;      /* sum over visits with changed coefficient of nnz(col i) */
+  double err;     /* 1/2 ||y - yhat||^2 */
+  double obj;     /* err + l2/2 ||x||^2 + l1 ||x||_1 */
+} oracle_colstat_t;
+
+/* cd.c:101-142 CoordinateDescent, reference arithmetic.
+ * x, y, yhat dense doubles; act[] = (float aTy, column id).                  */
+static int32_t cd_reference(const cview_t *A, const oracle_cfg_t *cfg,
+                            fkv_t *act, int32_t na, int32_t maxniters,
+                            double *x, double *yhat, int32_t item,
+                            uint32_t *lstate, fkv_t *tmp, int32_t *r_niters,
+                            int64_t *D, int64_t *U) {
+  int32_t t, rstatus = 0;
+  for (int32_t i = 0; i < na; i++) /* cd.c:108-110 */
+    add_spvec(A, (int32_t)act[i].val, x[act[i].val], yhat);
+
+  for (t = 0; t < maxniters; t++) {
+    double dltx = 0.0;
+    const fkv_t *visit = act;
+    if (cfg->order == ORDER_GLIBC)
+      shuffle_glibc(act, na); /* cd.c:115 */
+    else if (cfg->order == ORDER_LOCAL)
+      shuffle_local(act, na, lstate);
+    else if (cfg->order == ORDER_PERM) {
+      uint32_t key = oracle_perm_key(cfg->seed, (uint32_t)item, (uint32_t)t);
+      for (int32_t p = 0; p < na; p++)
+        tmp[p] = act[oracle_perm_index((uint32_t)p, (uint32_t)na, key)];
+      visit = tmp;
+    }
+    for (int32_t i = 0; i < na; i++) { /* cd.c:116-133 */
+      int32_t iI = (int32_t)visit[i].val;
+      double aTy = visit[i].key;
+      double aTa = A->cnorms[iI];
+      double xi = x[iI];
+      int64_t len = A->colptr[iI + 1] - A->colptr[iI];
+      int64_t touched = add_spvec(A, iI, -xi, yhat);
+      double ip = spvec_dot(A, iI, yhat);
+      double num = aTy - ip;
+      double newxi =
+          num > cfg->l1r ? (num - cfg->l1r) / ((aTa * aTa) + cfg->l2r) : 0.0;
+      touched += add_spvec(A, iI, newxi, yhat);
+      x[iI] = newxi;
+      dltx += (newxi - xi) * (newxi - xi);
+      *D += len;
+      if (touched) *U += len;
+    }
+    if (dltx < cfg->optTol) { /* cd.c:135-138 */
+      rstatus = 1;
+      break;
+    }
+  }
+  *r_niters = t + 1; /* cd.c:140 (also when maxniters == 0 or loop exhausted) */
+  return rstatus;
+}
+
+/* Engine-style arithmetic on the same algorithm: fp32 residual r = y - yhat,
+ * one fused pass per visit (num = a_i.r + x_i*sum(a_i^2)), same epsilon rule
+ * for which coefficients enter the residual (cd.c:27).  Used to bound what
+ * fp32 alone does to W; the GPU adds only a different summation order.        */
+static int32_t cd_fp32(const cview_t *A, const oracle_cfg_t *cfg, fkv_t *act,
+                       int32_t na, int32_t maxniters, float *x, float *r,
+                       int32_t item, uint32_t *lstate, fkv_t *tmp,
+                       int32_t *r_niters, int64_t *D, int64_t *U) {
+  int32_t t, rstatus = 0;
+  const float l1 = (float)cfg->l1r, l2 = (float)cfg->l2r;
+  const float eps = (float)ORACLE_EPS;
+  for (int32_t i = 0; i < na; i++) {
+    int32_t iI = (int32_t)act[i].val;
+    float xi = x[iI];
+    if (xi > eps || xi < -eps)
+      for (int64_t j = A->colptr[iI]; j < A->colptr[iI + 1]; j++)
+        r[A->colind[j]] -= xi * (A->colval ? A->colval[j] : 1.0f);
+  }
+  for (t = 0; t < maxniters; t++) {
+    float dltx = 0.0f;
+    const fkv_t *visit = act;
+    if (cfg->order == ORDER_GLIBC)
+      shuffle_glibc(act, na);
+    else if (cfg->order == ORDER_LOCAL)
+      shuffle_local(act, na, lstate);
+    else if (cfg->order == ORDER_PERM) {
+      uint32_t key = oracle_perm_key(cfg->seed, (uint32_t)item, (uint32_t)t);
+      for (int32_t p = 0; p < na; p++)
+        tmp[p] = act[oracle_perm_index((uint32_t)p, (uint32_t)na, key)];
+      visit = tmp;
+    }
+    for (int32_t i = 0; i < na; i++) {
+      int32_t iI = (int32_t)visit[i].val;
+      float cn = A->cnorms[iI];
+      float xi = x[iI];
+      float xeff = (xi > eps || xi < -eps) ? xi : 0.0f;
+      float dot = 0.0f, ss = 0.0f;
+      for (int64_t j = A->colptr[iI]; j < A->colptr[iI + 1]; j++) {
+        float v = A->colval ? A->colval[j] : 1.0f;
+        dot += v * r[A->colind[j]];
+        ss += v * v;
+      }
+      float num = dot + xeff * ss;
+      float newxi = num > l1 ? (num - l1) / (cn * cn + l2) : 0.0f;
+      float neff = (newxi > eps || newxi < -eps) ? newxi : 0.0f;
+      float d = neff - xeff;
+      int64_t len = A->colptr[iI + 1] - A->colptr[iI];
+      if (d != 0.0f) {
+        for (int64_t j = A->colptr[iI]; j < A->colptr[iI + 1]; j++)
+          r[A->colind[j]] -= d * (A->colval ? A->colval[j] : 1.0f);
+        *U += len;
+      }
+      *D += len;
+      x[iI] = newxi;
+      dltx += (newxi - xi) * (newxi - xi);
+    }
+    if (dltx < (float)cfg->optTol) {
+      rstatus = 1;
+      break;
+    }
+  }
+  *r_niters = t + 1;
+  return rstatus;
+}
+
+/* ------------------------------------------------------------------------ */
+/* estimate.c:328-558 EstimateModelCD (+ SaveModel's column view, :570-589)   */
+/* ------------------------------------------------------------------------ */
+/* Inputs: CSR (rowval may be NULL).  imodel_* : column view of a previous model
+ * (warm start, estimate.c:453-464) or NULL.  colsel: optional list of the
+ * columns to solve (others produce empty columns) -- the reference always
+ * solves all; the subset exists for bounded CPU-baseline samples.
+ * Outputs (malloc'd, release with oracle_free): colptr[ncols+1], colind, colval
+ * = column iC holds the regressors of item iC, ascending ids, float values.
+ * stats: optional array of ncols entries.  Returns ncols, or <0 on error.     */
+int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
+                        const int32_t *rowind, const float *rowval,
+                        const oracle_cfg_t *cfg, const int64_t *imodel_colptr,
+                        const int32_t *imodel_colind,
+                        const float *imodel_colval, int32_t imodel_ncols,
+                        int32_t ncolsel, const int32_t *colsel,
+                        int64_t **r_colptr, int32_t **r_colind,
+                        float **r_colval, oracle_colstat_t *stats,
+                        double *r_error, double *r_objval) {
+  const int64_t nnz = rowptr[nrows];
+  const int32_t ncols = oracle_ncols(nnz, rowind);
+  if (ncols <= 0) return -1;
+
+  /* CreateTrainingMatrix: column view + norms (setup.c:128-132) */
+  int64_t *colptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)ncols + 1));
+  int32_t *colind = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+  float *colval =
+      rowval ? (float *)malloc(sizeof(float) * (size_t)(nnz ? nnz : 1)) : NULL;
+  float *cnorms = (float *)malloc(sizeof(float) * (size_t)ncols);
+  oracle_transpose(nrows, ncols, rowptr, rowind, rowval, colptr, colind, colval);
+  oracle_col_norms(ncols, colptr, colval, cnorms);
+  cview_t A = {colptr, colind, colval, cnorms};
+
+  int32_t *nnzs = (int32_t *)calloc((size_t)ncols, sizeof(int32_t));
+  fkv_t **lists = (fkv_t **)calloc((size_t)ncols, sizeof(fkv_t *));
+  double error = 0.0, objval = 0.0;
+  const int32_t nwork = colsel ? ncolsel : ncols;
+  int nthreads = cfg->nthreads > 0 ? cfg->nthreads : 1;
+  if (stats) memset(stats, 0, sizeof(oracle_colstat_t) * (size_t)ncols);
+
+#pragma omp parallel num_threads(nthreads) reduction(+ : error, objval)
+  {
+    /* per-thread dense work vectors, estimate.c:382-385 */
+    double *x = (double *)calloc((size_t)ncols, sizeof(double));
+    double *y = (double *)calloc((size_t)nrows, sizeof(double));
+    double *yhat = (double *)calloc((size_t)nrows, sizeof(double));
+    double *ATy = (double *)calloc((size_t)ncols, sizeof(double));
+    float *xf = cfg->fp32 ? (float *)calloc((size_t)ncols, sizeof(float)) : NULL;
+    float *rf = cfg->fp32 ? (float *)calloc((size_t)nrows, sizeof(float)) : NULL;
+    fkv_t *act = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)ncols);
+    fkv_t *tmp = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)ncols);
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    uint32_t lstate = 0x9E3779B9u ^ (cfg->seed * 2654435761u) ^
+                      ((uint32_t)tid * 0x85EBCA6Bu + 1u);
+    if (lstate == 0) lstate = 1;
+
+#pragma omp for schedule(dynamic, 32) /* estimate.c:402 */
+    for (int32_t w = 0; w < nwork; w++) {
+      const int32_t iC = colsel ? colsel[w] : w;
+      const int64_t cs = colptr[iC], ce = colptr[iC + 1];
+      int64_t G = 0, D = 0, U = 0;
+
+      /* estimate.c:406-408 target vector */
+      for (int64_t j = cs; j < ce; j++)
+        y[colind[j]] = colval ? colval[j] : 1.0;
+
+      /* estimate.c:412-421: ATy[i] = a_i . y for ALL columns i.  ATY_GRAM
+       * computes the same vector through the users of column iC (sum over
+       * u in col iC of val * row_u); identical in exact arithmetic.           */
+      if (cfg->aty == ATY_FULLSCAN) {
+        for (int32_t i = 0; i < ncols; i++) {
+          double ip = 0.0;
+          if (colval)
+            for (int64_t j = colptr[i]; j < colptr[i + 1]; j++)
+              ip += colval[j] * y[colind[j]];
+          else
+            for (int64_t j = colptr[i]; j < colptr[i + 1]; j++)
+              ip += y[colind[j]];
+          ATy[i] = ip;
+        }
+        for (int64_t j = cs; j < ce; j++)
+          G += rowptr[colind[j] + 1] - rowptr[colind[j]];
+      } else {
+        for (int64_t j = cs; j < ce; j++) {
+          const int32_t u = colind[j];
+          const double v = colval ? colval[j] : 1.0;
+          for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++)
+            ATy[rowind[e]] += v * (rowval ? rowval[e] : 1.0);
+          G += rowptr[u + 1] - rowptr[u];
+        }
+      }
+
+      /* estimate.c:433-444 active set: strict '>' against l1r, diag excluded,
+       * key stored as float, x flagged -0.1 for the warm-start test          */
+      int32_t na = 0;
+      for (int32_t i = 0; i < ncols; i++) {
+        if (ATy[i] > cfg->l1r && i != iC) {
+          act[na].val = i;
+          act[na].key = (float)ATy[i];
+          na++;
+          x[i] = -0.1;
+        }
+      }
+
+      /* estimate.c:448-449 adaptive sweep cap */
+      int64_t cap = 50 * (ce - cs);
+      int32_t maxit = cap < cfg->maxniters ? (int32_t)cap : cfg->maxniters;
+
+      /* estimate.c:453-471 initial solution */
+      if (imodel_colptr && iC < imodel_ncols) {
+        for (int64_t j = imodel_colptr[iC]; j < imodel_colptr[iC + 1]; j++) {
+          int32_t k = imodel_colind[j];
+          if (k < ncols) x[k] = x[k] < 0. ? imodel_colval[j] : 0.0;
+        }
+        for (int32_t i = 0; i < na; i++) {
+          int64_t k = act[i].val;
+          x[k] = x[k] < 0. ? 0.0 : x[k];
+        }
+      } else {
+        for (int32_t i = 0; i < na; i++) x[act[i].val] = 0.0;
+      }
+
+      int32_t niters = 0, rstatus;
+      double soln_rNorm = 0.0;
+      if (!cfg->fp32) {
+        rstatus = cd_reference(&A, cfg, act, na, maxit, x, yhat, iC, &lstate,
+                               tmp, &niters, &D, &U);
+        /* estimate.c:477-481 */
+        for (int32_t i = 0; i < nrows; i++)
+          soln_rNorm += (y[i] - yhat[i]) * (y[i] - yhat[i]);
+      } else {
+        for (int64_t j = cs; j < ce; j++)
+          rf[colind[j]] = colval ? colval[j] : 1.0f;
+        for (int32_t i = 0; i < na; i++) xf[act[i].val] = (float)x[act[i].val];
+        rstatus = cd_fp32(&A, cfg, act, na, maxit, xf, rf, iC, &lstate, tmp,
+                          &niters, &D, &U);
+        for (int32_t i = 0; i < na; i++) x[act[i].val] = xf[act[i].val];
+        for (int32_t i = 0; i < nrows; i++)
+          soln_rNorm += (double)rf[i] * (double)rf[i];
+      }
+      soln_rNorm *= 0.5;
+      error += soln_rNorm;
+
+      /* estimate.c:483-489 objective */
+      double soln_obj = soln_rNorm;
+      for (int32_t i = 0; i < ncols; i++)
+        soln_obj += 0.5 * cfg->l2r * (x[i] * x[i]) + cfg->l1r * fabs(x[i]);
+      objval += soln_obj;
+
+      /* estimate.c:492-505 keep |x| > EPSILON, ascending i, float values */
+      int32_t nz = 0;
+      for (int32_t i = 0; i < ncols; i++)
+        if (fabs(x[i]) > ORACLE_EPS) nz++;
+      fkv_t *list = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)(nz ? nz : 1));
+      nz = 0;
+      for (int32_t i = 0; i < ncols; i++)
+        if (fabs(x[i]) > ORACLE_EPS) {
+          list[nz].key = (float)x[i];
+          list[nz].val = i;
+          nz++;
+        }
+      nnzs[iC] = nz;
+      lists[iC] = list;
+
+      if (stats) {
+        stats[iC].nacols = na;
+        stats[iC].sweeps = niters;
+        stats[iC].conv = rstatus;
+        stats[iC].nnzw = nz;
+        stats[iC].G = G;
+        stats[iC].D = D;
+        stats[iC].U = U;
+        stats[iC].err = soln_rNorm;
+        stats[iC].obj = soln_obj;
+      }
+
+      /* estimate.c:517-530 restore the work vectors (sparsely where the
+       * support is known; same end state as the reference's dense resets)    */
+      for (int64_t j = cs; j < ce; j++) y[colind[j]] = 0.0;
+      for (int32_t i = 0; i < na; i++) x[act[i].val] = 0.0;
+      if (imodel_colptr && iC < imodel_ncols)
+        for (int64_t j = imodel_colptr[iC]; j < imodel_colptr[iC + 1]; j++)
+          if (imodel_colind[j] < ncols) x[imodel_colind[j]] = 0.0;
+      if (cfg->aty == ATY_GRAM) {
+        for (int64_t j = cs; j < ce; j++) {
+          const int32_t u = colind[j];
+          for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++) ATy[rowind[e]] = 0.0;
+        }
+      }
+      if (!cfg->fp32)
+        memset(yhat, 0, sizeof(double) * (size_t)nrows);
+      else {
+        memset(rf, 0, sizeof(float) * (size_t)nrows);
+        for (int32_t i = 0; i < na; i++) xf[act[i].val] = 0.0f;
+      }
+    }
+    free(x);
+    free(y);
+    free(yhat);
+    free(ATy);
+    free(xf);
+    free(rf);
+    free(act);
+    free(tmp);
+  }
+
+  /* estimate.c:570-589 SaveModel, column view */
+  int64_t tnnz = 0;
+  for (int32_t c = 0; c < ncols; c++) tnnz += nnzs[c];
+  int64_t *wptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)ncols + 1));
+  int32_t *wind = (int32_t *)malloc(sizeof(int32_t) * (size_t)(tnnz ? tnnz : 1));
+  float *wval = (float *)malloc(sizeof(float) * (size_t)(tnnz ? tnnz : 1));
+  wptr[0] = 0;
+  tnnz = 0;
+  for (int32_t c = 0; c < ncols; c++) {
+    for (int32_t k = 0; k < nnzs[c]; k++, tnnz++) {
+      wind[tnnz] = (int32_t)lists[c][k].val;
+      wval[tnnz] = lists[c][k].key;
+    }
+    wptr[c + 1] = tnnz;
+    free(lists[c]);
+  }
+  free(lists);
+  free(nnzs);
+  free(colptr);
+  free(colind);
+  free(colval);
+  free(cnorms);
+  *r_colptr = wptr;
+  *r_colind = wind;
+  *r_colval = wval;
+  if (r_error) *r_error = error;
+  if (r_objval) *r_objval = objval;
+  return ncols;
+}
+
+void oracle_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------ */
+/* predict.c:15-71 GetRecommendations                                         */
+/* ------------------------------------------------------------------------ */
+static int fkv_desc(const void *a, const void *b) {
+  const fkv_t *x = (const fkv_t *)a, *y = (const fkv_t *)b;
+  if (x->key > y->key) return -1;
+  if (x->key < y->key) return 1;
+  return 0;
+}
+/* stable descending sort by key (merge sort): ties keep insertion order.    */
+static void fkv_sortd_stable(fkv_t *a, int64_t n) {
+  if (n < 2) return;
+  fkv_t *b = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)n);
+  for (int64_t w = 1; w < n; w *= 2) {
+    for (int64_t lo = 0; lo < n; lo += 2 * w) {
+      int64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+      int64_t i = lo, j = mid, k = lo;
+      while (i < mid && j < hi) b[k++] = (fkv_desc(&a[j], &a[i]) < 0) ? a[j++] : a[i++];
+      while (i < mid) b[k++] = a[i++];
+      while (j < hi) b[k++] = a[j++];
+    }
+    memcpy(a, b, sizeof(fkv_t) * (size_t)n);
+  }
+  free(b);
+}
+
+/* W given by its ROW view (rowptr/rowind/rowval over ncols rows): the score of
+ * candidate k is sum over history items i of rating_i * W[i,k].  float
+ * accumulation in history order, history excluded, sort desc, take N.
+ * marker/cand are caller scratch of ncols entries (marker preset to -1);
+ * both are restored on return.                                                */
+static int32_t get_recs(int32_t ncols, const int64_t *rowptr,
+                        const int32_t *rowind, const float *rowval,
+                        int32_t nratings, const int32_t *itemids,
+                        const float *ratings, int32_t nrcmds, int32_t *rids,
+                        float *rscores, int32_t *marker, fkv_t *cand) {
+  for (int32_t r = 0; r < nratings; r++) /* predict.c:35-38 */
+    if (itemids[r] < ncols && itemids[r] >= 0) marker[itemids[r]] = -2;
+  int32_t ncand = 0;
+  for (int32_t r = 0; r < nratings; r++) { /* predict.c:40-58 */
+    int32_t i = itemids[r];
+    if (i >= ncols || i < 0) continue; /* the reference's guard (&&) never
+                       fires; out-of-range ids are undefined behaviour there */
+    float rating = ratings ? ratings[r] : 1.0f;
+    for (int64_t j = rowptr[i]; j < rowptr[i + 1]; j++) {
+      int32_t k = rowind[j];
+      if (marker[k] == -2) continue;
+      if (marker[k] == -1) {
+        cand[ncand].val = k;
+        cand[ncand].key = 0.0f;
+        marker[k] = ncand++;
+      }
+      cand[marker[k]].key += rating * rowval[j];
+    }
+  }
+  fkv_sortd_stable(cand, ncand); /* predict.c:60 gk_fkvsortd */
+  int32_t n = ncand < nrcmds ? ncand : nrcmds;
+  for (int32_t r = 0; r < n; r++) {
+    rids[r] = (int32_t)cand[r].val;
+    rscores[r] = cand[r].key;
+  }
+  for (int32_t r = 0; r < ncand; r++) marker[cand[r].val] = -1;
+  for (int32_t r = 0; r < nratings; r++)
+    if (itemids[r] < ncols && itemids[r] >= 0) marker[itemids[r]] = -1;
+  return n;
+}
+
+int32_t oracle_get_topn(int32_t ncols, const int64_t *wrowptr,
+                        const int32_t *wrowind, const float *wrowval,
+                        int32_t nratings, const int32_t *itemids,
+                        const float *ratings, int32_t nrcmds, int32_t *rids,
+                        float *rscores) {
+  int32_t *marker = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
+  fkv_t *cand = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)ncols);
+  for (int32_t i = 0; i < ncols; i++) marker[i] = -1;
+  int32_t n = get_recs(ncols, wrowptr, wrowind, wrowval, nratings, itemids,
+                       ratings, nrcmds, rids, rscores, marker, cand);
+  free(marker);
+  free(cand);
+  return n;
+}
+
+/* pyapi.c:530-563 Py_SLIM_Predict: top-N for every row of the history matrix;
+ * out[u*nrcmds + r], untouched slots keep the caller's fill.                  */
+int32_t oracle_predict(int32_t ncols, const int64_t *wrowptr,
+                       const int32_t *wrowind, const float *wrowval,
+                       int32_t nusers, const int64_t *hptr, const int32_t *hind,
+                       const float *hval, int32_t nrcmds, int32_t *out,
+                       float *scores) {
+  int32_t *marker = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
+  fkv_t *cand = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)ncols);
+  int32_t *rids = (int32_t *)malloc(sizeof(int32_t) * (size_t)nrcmds);
+  float *rsc = (float *)malloc(sizeof(float) * (size_t)nrcmds);
+  for (int32_t i = 0; i < ncols; i++) marker[i] = -1;
+  for (int32_t u = 0; u < nusers; u++) {
+    int32_t n = get_recs(ncols, wrowptr, wrowind, wrowval,
+                         (int32_t)(hptr[u + 1] - hptr[u]), hind + hptr[u],
+                         hval ? hval + hptr[u] : NULL, nrcmds, rids, rsc, marker,
+                         cand);
+    for (int32_t r = 0; r < n; r++) {
+      out[(int64_t)u * nrcmds + r] = rids[r];
+      scores[(int64_t)u * nrcmds + r] = rsc[r];
+    }
+  }
+  free(marker);
+  free(cand);
+  free(rids);
+  free(rsc);
+  return 1;
+}
+
+/* api.c:215-245 SLIM_DetermineHeadAndTail: 0 = head (most popular items that
+ * cover the first half of the ratings), 1 = tail.  gk_ikvsortd tie order is
+ * undefined upstream; stable (ascending id among equal counts) here.          */
+typedef struct {
+  int32_t key;
+  int32_t val;
+} ikv_t;
+static int ikv_desc(const void *a, const void *b) {
+  const ikv_t *x = (const ikv_t *)a, *y = (const ikv_t *)b;
+  if (x->key != y->key) return x->key > y->key ? -1 : 1;
+  return x->val < y->val ? -1 : (x->val > y->val);
+}
+void oracle_head_tail(int32_t nrows, int32_t ncols, const int64_t *rowptr,
+                      const int32_t *rowind, int32_t *fmarker) {
+  ikv_t *cand = (ikv_t *)malloc(sizeof(ikv_t) * (size_t)ncols);
+  for (int32_t c = 0; c < ncols; c++) {
+    cand[c].key = 0;
+    cand[c].val = c;
+    fmarker[c] = 1;
+  }
+  for (int64_t j = 0; j < rowptr[nrows]; j++) cand[rowind[j]].key++;
+  qsort(cand, (size_t)ncols, sizeof(ikv_t), ikv_desc);
+  int64_t cnnz = rowptr[nrows] / 2;
+  for (int32_t c = 0; c < ncols && cnnz > 0; c++) {
+    fmarker[cand[c].val] = 0;
+    cnnz -= cand[c].key;
+  }
+  free(cand);
+}
+
+/* HR / ARHR evaluation: pyapi.c:309-366 (== slim_mselect.c:122-187; users with
+ * an empty test row are skipped, unlike slim_predict.c:226).
+ * res[0]=HR res[1]=HR_head res[2]=HR_tail res[3]=ARHR; counts[0]=nvalid
+ * counts[1]=nvalid_head counts[2]=nvalid_tail.                                */
+void oracle_eval(int32_t ncols, const int64_t *wrowptr, const int32_t *wrowind,
+                 const float *wrowval, int32_t nusers, const int64_t *trnptr,
+                 const int32_t *trnind, const float *trnval,
+                 const int64_t *tstptr, const int32_t *tstind, int32_t nrcmds,
+                 int32_t fm_ncols, double *res, int32_t *counts) {
+  int32_t mcols = ncols > fm_ncols ? ncols : fm_ncols;
+  int32_t *marker = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
+  fkv_t *cand = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)ncols);
+  int32_t *rids = (int32_t *)malloc(sizeof(int32_t) * (size_t)nrcmds);
+  float *rsc = (float *)malloc(sizeof(float) * (size_t)nrcmds);
+  int32_t *rmarker = (int32_t *)malloc(sizeof(int32_t) * (size_t)mcols);
+  int32_t *fmarker = (int32_t *)malloc(sizeof(int32_t) * (size_t)mcols);
+  for (int32_t i = 0; i < ncols; i++) marker[i] = -1;
+  for (int32_t i = 0; i < mcols; i++) rmarker[i] = -1;
+  oracle_head_tail(nusers, mcols, trnptr, trnind, fmarker);
+
+  float hr[3] = {0, 0, 0}, arhr = 0;
+  int32_t nvalid = 0, nvh = 0, nvt = 0;
+  for (int32_t u = 0; u < nusers; u++) {
+    if (tstptr[u + 1] - tstptr[u] < 1) continue;
+    int32_t n = get_recs(ncols, wrowptr, wrowind, wrowval,
+                         (int32_t)(trnptr[u + 1] - trnptr[u]), trnind + trnptr[u],
+                         trnval ? trnval + trnptr[u] : NULL, nrcmds, rids, rsc,
+                         marker, cand);
+    nvalid++;
+    int is_t = 0, is_h = 0;
+    int32_t ntrue[2] = {0, 0}, nhits[3] = {0, 0, 0};
+    float larhr = 0, baseline = 0;
+    for (int64_t z = tstptr[u]; z < tstptr[u + 1]; z++) {
+      rmarker[tstind[z]] = u;
+      ntrue[fmarker[tstind[z]]]++;
+      if (fmarker[tstind[z]]) is_t = 1; else is_h = 1;
+      baseline += 1.0 / (1.0 + z - tstptr[u]);
+    }
+    nvt += is_t;
+    nvh += is_h;
+    for (int32_t r = 0; r < n; r++)
+      if (rmarker[rids[r]] == u) {
+        nhits[fmarker[rids[r]]]++;
+        nhits[2]++;
+        larhr += 1.0 / (1.0 + r);
+      }
+    hr[0] += (nhits[0] > 0 ? 1.0 * nhits[0] / ntrue[0] : 0.0);
+    hr[1] += (nhits[1] > 0 ? 1.0 * nhits[1] / ntrue[1] : 0.0);
+    hr[2] += 1.0 * nhits[2] / (tstptr[u + 1] - tstptr[u]);
+    arhr += larhr / baseline;
+  }
+  /* the reference keeps these in float (pyapi.c:223-230,360-363) */
+  float all_hr = nvalid > 0 ? hr[2] / nvalid : 0;
+  float head_hr = nvh > 0 ? hr[0] / nvh : 0;
+  float tail_hr = nvt > 0 ? hr[1] / nvt : 0;
+  arhr = nvalid > 0 ? arhr / nvalid : 0;
+  res[0] = all_hr;
+  res[1] = head_hr;
+  res[2] = tail_hr;
+  res[3] = arhr;
+  counts[0] = nvalid;
+  counts[1] = nvh;
+  counts[2] = nvt;
+  free(marker);
+  free(cand);
+  free(rids);
+  free(rsc);
+  free(rmarker);
+  free(fmarker);
+}
+
+/* re-seed libc rand() so ORDER_GLIBC runs are repeatable inside one process
+ * (a fresh reference process starts from srand(1), the C default).            */
+void oracle_srand(uint32_t s) { srand(s); }
+
+int32_t oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,351 @@
+// cd_wave.hpp -- the SLIM coordinate-descent solver as HIP for gfx950 (CDNA4).
+//
+// One wavefront (64 lanes) owns one item column iC at a time and runs the whole
+// per-item pipeline of the reference's EstimateModelCD loop body
+// (src/libslim/estimate.c:402-530) + CoordinateDescent (src/libslim/cd.c:101-142):
+//
+//   1. y  <- column iC (scatter into the residual r = y - yhat)   estimate.c:406-408
+//   2. aTy <- R^T y through the users of column iC ("Gram column":
+//        sum over u in col iC of val * row_u); the reference scans the whole
+//        matrix per item instead (estimate.c:412-421), same vector
+//   3. active list {i != iC : aTy_i > l1} by ballot compaction, ascending ids
+//                                                                 estimate.c:433-444
+//   4. warm start from the previous model's column iC            estimate.c:453-471
+//   5. CD sweeps, visiting the active list through the keyed permutation of
+//      cd_perm.hpp; one fused pass per visit:
+//        dot = a_i . r   (lane-strided column walk + DPP wave reduction)
+//        num = dot + x_i * |a_i|^2     ( == aTy_i - a_i.(yhat - x_i a_i), cd.c:121-123 )
+//        x_i' = num > l1 ? (num - l1) / (cnorm_i^2 + l2) : 0      cd.c:124-127
+//        r -= (x_i' - x_i) a_i   only when the coefficient changed  cd.c:27,121,128
+//      stop when sum (x_i'-x_i)^2 < optTol                         cd.c:135
+//   6. 1/2||r||^2, objective, compaction of |x| > 1e-7 into the output arena
+//                                                                 estimate.c:477-505
+//
+// Work vectors (r over users, aTy/ids and x over items) live in LDS when they
+// fit (USE_LDS) and in a per-wave HBM slab otherwise.  Wavefronts are
+// persistent and pull item columns from an atomic queue ordered by descending
+// cost (the device form of `omp for schedule(dynamic,32)`, estimate.c:402).
+// Arithmetic is fp32 (matrix values, residual, dot accumulators); no MFMA --
+// this is sparse dot/axpy, bound by gather latency and HBM/L2 bandwidth.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "cd_perm.hpp"
+
+namespace slimamd {
+
+struct DevMatrix {
+  int32_t nrows, ncols;
+  int64_t nnz;
+  const int64_t* rowptr;  // CSR
+  const int32_t* rowind;
+  const float* rowval;    // nullptr: binary matrix
+  const int64_t* colptr;  // CSC, user ids ascending inside each column
+  const int32_t* colind;
+  const float* colval;    // nullptr iff rowval is
+  const float* cnorm;     // (float)sqrt(fp32 sum of squares)     setup.c:130
+  const float* csq;       // fp32 sum of squares of the column
+};
+
+struct SolveArgs {
+  float l1, l2, opt_tol;
+  int32_t maxniters;
+  uint32_t seed;
+  // work list (item ids, most expensive first) and the queue head
+  const int32_t* order;
+  int32_t nwork;
+  int32_t* queue;
+  // warm start: column view of the previous model (nullptr: cold start)
+  const int64_t* icolptr;
+  const int32_t* icolind;
+  const float* icolval;
+  int32_t incols;
+  // per-wave HBM slab for the work vectors (HBM kernel only)
+  float* slab;
+  int64_t slab_stride;  // floats per wavefront
+  int32_t nrows_pad, ncols_pad;
+  // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
+  int32_t* out_cnt;
+  int64_t* out_off;
+  int32_t* out_ind;
+  float* out_val;
+  unsigned long long* out_cursor;
+  int64_t out_cap;
+  int32_t* overflow;
+  // per-column counters
+  int32_t* st_na;
+  int32_t* st_sweeps;
+  int32_t* st_conv;
+  int64_t* st_G;
+  int64_t* st_D;
+  int64_t* st_U;
+  float* st_err;
+  float* st_obj;
+};
+
+constexpr float kEps = 1e-7f;  // def.h:14
+
+// ---- wave-level primitives ---------------------------------------------------
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ float uni(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ int64_t uni(int64_t v) {
+  uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int lane_bcast(int v, int src) {
+  return __builtin_amdgcn_readlane(v, src);
+}
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ int64_t lane_bcast(int64_t v, int src) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the 64 lanes; the result is wave-uniform.  Four DPP butterfly steps
+// inside each 16-lane row (quad xor 1, quad xor 2, half-row mirror, row
+// mirror), then the four row totals are combined through the scalar unit.
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+
+// Lanes of one wavefront exchange data through r/aty/x.  LDS requests of a wave
+// are served in issue order, so the LDS form only has to stop the compiler
+// from reordering; the HBM form needs the stores of every lane visible to the
+// whole wave (shared vector L1 of the CU) before the next loads.
+template <bool USE_LDS>
+__device__ __forceinline__ void wave_sync() {
+  if (USE_LDS) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- the kernel ---------------------------------------------------------------
+
+template <bool USE_LDS, bool HAS_VAL>
+__global__ __launch_bounds__(64) void cd_wave_kernel(const DevMatrix A, const SolveArgs S) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+
+  float* r;      // residual y - yhat over users
+  float* aty;    // dense aTy over items, then reused as the active id list
+  float* x;      // coefficients of the active list (slot order = ascending id)
+  if (USE_LDS) {
+    r = reinterpret_cast<float*>(smem);
+  } else {
+    r = S.slab + (int64_t)blockIdx.x * S.slab_stride;
+  }
+  aty = r + S.nrows_pad;
+  x = aty + S.ncols_pad;
+  int* ids = reinterpret_cast<int*>(aty);
+
+  const int nrows = A.nrows, ncols = A.ncols;
+  const float l1 = S.l1, l2 = S.l2;
+
+  for (;;) {
+    int w = 0;
+    if (lane == 0) w = atomicAdd(S.queue, 1);
+    w = uni(w);
+    if (w >= S.nwork) break;
+    const int iC = uni(S.order[w]);
+    const int64_t cs = uni(A.colptr[iC]), ce = uni(A.colptr[iC + 1]);
+
+    // -- clear the work vectors
+    for (int u = lane; u < nrows; u += 64) r[u] = 0.0f;
+    for (int i = lane; i < ncols; i += 64) aty[i] = 0.0f;
+    wave_sync<USE_LDS>();
+
+    // -- 1+2: y scatter and Gram column.  64 users of the column per step;
+    //    each user's row is then spread over the lanes (ids inside a row are
+    //    distinct, rows can collide -> float atomics, order-free for the
+    //    integer-valued ratings of every shipped dataset)
+    int64_t G = 0;
+    for (int64_t jb = cs; jb < ce; jb += 64) {
+      const int64_t j = jb + lane;
+      const bool ok = j < ce;
+      const int u_l = ok ? A.colind[j] : 0;
+      const float v_l = ok ? (HAS_VAL ? A.colval[j] : 1.0f) : 0.0f;
+      const int64_t rs_l = ok ? A.rowptr[u_l] : 0;
+      const int64_t re_l = ok ? A.rowptr[u_l + 1] : 0;
+      if (ok) r[u_l] = v_l;
+      const int cnt = (int)((ce - jb) < 64 ? (ce - jb) : 64);
+      for (int k = 0; k < cnt; ++k) {
+        const int64_t rs = lane_bcast(rs_l, k), re = lane_bcast(re_l, k);
+        const float v = lane_bcast(v_l, k);
+        G += re - rs;
+        for (int64_t e = rs + lane; e < re; e += 64) {
+          const float rv = HAS_VAL ? A.rowval[e] : 1.0f;
+          atomicAdd(&aty[A.rowind[e]], v * rv);
+        }
+      }
+    }
+    wave_sync<USE_LDS>();
+
+    // -- 3: active list by ballot compaction (in place: slot <= item id)
+    int na = 0;
+    for (int base = 0; base < ncols; base += 64) {
+      const int i = base + lane;
+      const float a = i < ncols ? aty[i] : 0.0f;
+      const bool act = (i < ncols) && (i != iC) && (a > l1);
+      const uint64_t m = __ballot(act);
+      wave_sync<USE_LDS>();  // every lane has consumed its aty[i] before slots are rewritten
+      if (act) {
+        const int slot = na + __popcll(m & lane_lt);
+        ids[slot] = i;
+        x[slot] = 0.0f;
+      }
+      na += __popcll(m);
+    }
+    wave_sync<USE_LDS>();
+
+    // -- 4: warm start.  imodel column iC is ascending; binary-search each of
+    //    its ids in the active list, then fold the non-zero x into r
+    if (S.icolptr != nullptr && iC < S.incols) {
+      const int64_t ws = uni(S.icolptr[iC]), we = uni(S.icolptr[iC + 1]);
+      for (int64_t e = ws + lane; e < we; e += 64) {
+        const int k = S.icolind[e];
+        int lo = 0, hi = na;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (ids[mid] < k) lo = mid + 1; else hi = mid;
+        }
+        if (lo < na && ids[lo] == k) x[lo] = S.icolval[e];
+      }
+      wave_sync<USE_LDS>();
+      for (int q = 0; q < na; ++q) {  // cd.c:108-110
+        const float xi = uni(x[q]);
+        if (xi > kEps || xi < -kEps) {
+          const int i = uni(ids[q]);
+          const int64_t s = uni(A.colptr[i]), t = uni(A.colptr[i + 1]);
+          for (int64_t e = s + lane; e < t; e += 64)
+            r[A.colind[e]] -= xi * (HAS_VAL ? A.colval[e] : 1.0f);
+          wave_sync<USE_LDS>();
+        }
+      }
+    }
+
+    // -- 5: sweeps
+    const int64_t cap = 50 * (ce - cs);  // estimate.c:448-449
+    const int maxit = cap < (int64_t)S.maxniters ? (int)cap : S.maxniters;
+    int t = 0, conv = 0;
+    int64_t D = 0, U = 0;
+    for (; t < maxit; ++t) {
+      float dlt = 0.0f;
+      const PermCtx pc = perm_make((uint32_t)na, perm_key(S.seed, (uint32_t)iC, (uint32_t)t));
+      for (int p = 0; p < na; ++p) {
+        const int q = (int)perm_index(pc, (uint32_t)p);
+        const int i = uni(ids[q]);
+        const float xi = uni(x[q]);
+        const int64_t s = uni(A.colptr[i]), e_end = uni(A.colptr[i + 1]);
+        const float cn = uni(A.cnorm[i]);
+        const float sq = uni(A.csq[i]);
+
+        float acc = 0.0f;
+        for (int64_t e = s + lane; e < e_end; e += 64) {
+          const float v = HAS_VAL ? A.colval[e] : 1.0f;
+          acc += v * r[A.colind[e]];
+        }
+        const float dot = wave_sum(acc);
+
+        const float xeff = (xi > kEps || xi < -kEps) ? xi : 0.0f;
+        const float num = dot + xeff * sq;
+        const float nx = num > l1 ? (num - l1) / (cn * cn + l2) : 0.0f;
+        const float neff = (nx > kEps || nx < -kEps) ? nx : 0.0f;
+        const float d = neff - xeff;
+        D += e_end - s;
+        if (d != 0.0f) {
+          for (int64_t e = s + lane; e < e_end; e += 64)
+            r[A.colind[e]] -= d * (HAS_VAL ? A.colval[e] : 1.0f);
+          U += e_end - s;
+          wave_sync<USE_LDS>();
+        }
+        if (lane == 0) x[q] = nx;
+        dlt += (nx - xi) * (nx - xi);
+      }
+      wave_sync<USE_LDS>();
+      if (dlt < S.opt_tol) {  // cd.c:135-138
+        conv = 1;
+        break;
+      }
+    }
+    const int niters = t + 1;  // cd.c:140
+
+    // -- 6: loss terms and output
+    float e2 = 0.0f;
+    for (int u = lane; u < nrows; u += 64) {
+      const float rv = r[u];
+      e2 += rv * rv;
+    }
+    float reg = 0.0f;
+    int nz = 0;
+    for (int base = 0; base < na; base += 64) {
+      const int q = base + lane;
+      const float xv = q < na ? x[q] : 0.0f;
+      reg += 0.5f * l2 * xv * xv + l1 * fabsf(xv);
+      nz += __popcll(__ballot(fabsf(xv) > kEps));
+    }
+    const float err = 0.5f * wave_sum(e2);
+    const float obj = err + wave_sum(reg);
+
+    unsigned long long off = 0;
+    if (lane == 0) off = atomicAdd(S.out_cursor, (unsigned long long)nz);
+    off = (unsigned long long)uni((int64_t)off);
+    const bool fits = (int64_t)(off + (unsigned long long)nz) <= S.out_cap;
+    if (fits) {
+      int wpos = 0;
+      for (int base = 0; base < na; base += 64) {
+        const int q = base + lane;
+        const float xv = q < na ? x[q] : 0.0f;
+        const bool keep = fabsf(xv) > kEps;
+        const uint64_t m = __ballot(keep);
+        if (keep) {
+          const int64_t dst = (int64_t)off + wpos + __popcll(m & lane_lt);
+          S.out_ind[dst] = ids[q];
+          S.out_val[dst] = xv;
+        }
+        wpos += __popcll(m);
+      }
+    }
+    if (lane == 0) {
+      if (!fits) atomicExch(S.overflow, 1);
+      S.out_cnt[iC] = fits ? nz : -nz - 1;
+      S.out_off[iC] = (int64_t)off;
+      S.st_na[iC] = na;
+      S.st_sweeps[iC] = niters;
+      S.st_conv[iC] = conv;
+      S.st_G[iC] = G;
+      S.st_D[iC] = D;
+      S.st_U[iC] = U;
+      S.st_err[iC] = err;
+      S.st_obj[iC] = obj;
+    }
+    wave_sync<USE_LDS>();
+  }
+}
+
+}  // namespace slimamd

@@ -1,0 +1,765 @@
+// engine.hip -- HBM staging of the training matrix and the CD solve driver.
+//
+// Staging is the device form of CreateTrainingMatrix
+// (/root/reference/src/libslim/setup.c:109-135): the caller's CSR is copied to
+// HBM once (or adopted if it already lives there), the column view is built by
+// a stable radix sort on the item id (keeps user ids ascending inside every
+// column, which is what gk_csr_CreateIndex + slim_csr_SortIndices guarantee,
+// setup.c:128,132), and the column norms are reduced one wavefront per column
+// (gk_csr_ComputeNorms, setup.c:130).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "cd_wave.hpp"
+#include "engine.hpp"
+#include "host_csr.hpp"
+
+// ---- the opaque handle ---------------------------------------------------------
+struct slimgpu_matrix {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int32_t nrows = 0, ncols = 0;
+  int64_t nnz = 0;
+  bool binary = false;
+  bool owns_csr = false;
+  // CSR
+  int64_t* d_rowptr = nullptr;
+  int32_t* d_rowind = nullptr;
+  float* d_rowval = nullptr;
+  // CSC + per-column scalars
+  int64_t* d_colptr = nullptr;
+  int32_t* d_colind = nullptr;
+  float* d_colval = nullptr;
+  float* d_cnorm = nullptr;
+  float* d_csq = nullptr;
+  std::vector<int64_t> h_cost;  // scheduling proxy per column (Gram work G)
+  double setup_ms = 0;
+  int num_cus = 256;
+  // workspace reused by successive solves
+  struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+  };
+  Buf ws_order, ws_cnt, ws_off, ws_stat_i, ws_stat_l, ws_stat_f, ws_misc, ws_arena_i, ws_arena_v,
+      ws_slab, ws_icolptr, ws_icolind, ws_icolval;
+};
+
+namespace slimamd {
+
+namespace {
+
+thread_local slimgpu_stats_t g_stats;
+thread_local ColumnStats g_colstats;
+
+struct HipError {
+  hipError_t code;
+  std::string where;
+};
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) throw HipError{_e, std::string(#expr)};                  \
+  } while (0)
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+int32_t status_of(const HipError& e) {
+  return e.code == hipErrorOutOfMemory ? SLIM_ERROR_MEMORY : SLIM_ERROR;
+}
+
+void report(const HipError& e, const char* what) {
+  set_error(std::string(what) + ": HIP error '" + hipGetErrorString(e.code) + "' in " + e.where +
+            " -- the SLIM CD path needs a gfx950 GPU; there is no CPU fallback");
+}
+
+template <class T>
+T* dev_alloc(size_t n) {
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, sizeof(T) * (n ? n : 1)));
+  return static_cast<T*>(p);
+}
+
+// grow-only workspace buffer
+template <class T>
+T* ws_get(slimgpu_matrix::Buf& b, size_t n) {
+  const size_t need = sizeof(T) * (n ? n : 1);
+  if (b.bytes < need) {
+    if (b.p) HIP_TRY(hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    HIP_TRY(hipMalloc(&b.p, need));
+    b.bytes = need;
+  }
+  return static_cast<T*>(b.p);
+}
+
+// ---- staging kernels -----------------------------------------------------------
+
+__global__ void k_max_index(const int32_t* __restrict__ ind, int64_t n, int32_t* out) {
+  int32_t m = -1;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+       k += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, ind[k]);
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// key = item id, payload = (user id << 32 | value bits); one wavefront per row
+__global__ void k_pack_rows(int32_t nrows, const int64_t* __restrict__ rowptr,
+                            const int32_t* __restrict__ rowind,
+                            const float* __restrict__ rowval, uint32_t* __restrict__ keys,
+                            uint64_t* __restrict__ payload) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t u = wave; u < nrows; u += nwaves) {
+    const int64_t s = rowptr[u], e = rowptr[u + 1];
+    for (int64_t k = s + lane; k < e; k += 64) {
+      keys[k] = (uint32_t)rowind[k];
+      const uint32_t bits = rowval ? __float_as_uint(rowval[k]) : 0x3F800000u;
+      payload[k] = ((uint64_t)(uint32_t)u << 32) | bits;
+    }
+  }
+}
+
+__global__ void k_unpack_cols(int64_t nnz, const uint64_t* __restrict__ payload,
+                              int32_t* __restrict__ colind, float* __restrict__ colval) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t p = payload[k];
+    colind[k] = (int32_t)(p >> 32);
+    if (colval) colval[k] = __uint_as_float((uint32_t)p);
+  }
+}
+
+// colptr from the sorted keys: entry k opens every column in (key[k-1], key[k]]
+__global__ void k_col_offsets(int64_t nnz, int32_t ncols, const uint32_t* __restrict__ keys,
+                              int64_t* __restrict__ colptr) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= nnz;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lo = k == 0 ? 0 : (int64_t)keys[k - 1] + 1;
+    const int64_t hi = k == nnz ? (int64_t)ncols : (int64_t)keys[k];
+    for (int64_t c = lo; c <= hi; ++c) colptr[c] = k;
+  }
+}
+
+// one wavefront per column: fp32 sum of squares, norm, and the Gram work G
+__global__ void k_col_scalars(int32_t ncols, const int64_t* __restrict__ colptr,
+                              const int32_t* __restrict__ colind,
+                              const float* __restrict__ colval,
+                              const int64_t* __restrict__ rowptr, float* __restrict__ csq,
+                              float* __restrict__ cnorm, int64_t* __restrict__ cost) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t c = wave; c < ncols; c += nwaves) {
+    const int64_t s = colptr[c], e = colptr[c + 1];
+    float ss = 0.0f;
+    int64_t g = 0;
+    for (int64_t k = s + lane; k < e; k += 64) {
+      const float v = colval ? colval[k] : 1.0f;
+      ss += v * v;
+      const int32_t u = colind[k];
+      g += rowptr[u + 1] - rowptr[u];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      ss += __shfl_xor(ss, off);
+      g += __shfl_xor(g, off);
+    }
+    if (lane == 0) {
+      if (!colval) ss = (float)(e - s);
+      csq[c] = ss;
+      cnorm[c] = sqrtf(ss);
+      cost[c] = g;
+    }
+  }
+}
+
+int grid_for(int64_t n, int block, int cap_blocks) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap_blocks) g = cap_blocks;
+  return (int)g;
+}
+
+void pick_device(slimgpu_matrix* m, const LearnOptions& opt) {
+  int count = 0;
+  HIP_TRY(hipGetDeviceCount(&count));
+  if (count <= 0) throw HipError{hipErrorNoDevice, "hipGetDeviceCount"};
+  if (opt.device >= 0) {
+    HIP_TRY(hipSetDevice(opt.device));
+    m->device = opt.device;
+  } else {
+    HIP_TRY(hipGetDevice(&m->device));
+  }
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, m->device));
+  m->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+}
+
+// Build CSC + scalars from the device CSR of m (nrows/nnz/ncols already set).
+void build_column_view(slimgpu_matrix* m) {
+  hipStream_t st = m->stream;
+  const int64_t nnz = m->nnz;
+  m->d_colptr = dev_alloc<int64_t>((size_t)m->ncols + 1);
+  m->d_colind = dev_alloc<int32_t>((size_t)nnz);
+  m->d_colval = m->binary ? nullptr : dev_alloc<float>((size_t)nnz);
+  m->d_cnorm = dev_alloc<float>((size_t)m->ncols);
+  m->d_csq = dev_alloc<float>((size_t)m->ncols);
+  int64_t* d_cost = dev_alloc<int64_t>((size_t)m->ncols);
+
+  if (nnz > 0) {
+    if (nnz > 0xFFFFFFF0ll) throw HipError{hipErrorInvalidValue, "nnz >= 2^32 not supported"};
+    uint32_t* keys_in = dev_alloc<uint32_t>((size_t)nnz);
+    uint32_t* keys_out = dev_alloc<uint32_t>((size_t)nnz);
+    uint64_t* pay_in = dev_alloc<uint64_t>((size_t)nnz);
+    uint64_t* pay_out = dev_alloc<uint64_t>((size_t)nnz);
+    const int cap = m->num_cus * 16;
+    hipLaunchKernelGGL(k_pack_rows, dim3(grid_for((int64_t)m->nrows * 64, 256, cap)), dim3(256), 0,
+                       st, m->nrows, m->d_rowptr, m->d_rowind, m->d_rowval, keys_in, pay_in);
+    HIP_TRY(hipGetLastError());
+    unsigned bits = 1;
+    while ((1ull << bits) < (unsigned long long)m->ncols) ++bits;
+    size_t tmp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, pay_in, pay_out,
+                                      (size_t)nnz, 0u, bits, st));
+    void* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
+    HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, pay_in, pay_out,
+                                      (size_t)nnz, 0u, bits, st));
+    hipLaunchKernelGGL(k_unpack_cols, dim3(grid_for(nnz, 256, cap)), dim3(256), 0, st, nnz,
+                       pay_out, m->d_colind, m->d_colval);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_col_offsets, dim3(grid_for(nnz + 1, 256, cap)), dim3(256), 0, st, nnz,
+                       m->ncols, keys_out, m->d_colptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipFree(tmp));
+    HIP_TRY(hipFree(keys_in));
+    HIP_TRY(hipFree(keys_out));
+    HIP_TRY(hipFree(pay_in));
+    HIP_TRY(hipFree(pay_out));
+  } else {
+    HIP_TRY(hipMemsetAsync(m->d_colptr, 0, sizeof(int64_t) * ((size_t)m->ncols + 1), st));
+  }
+  hipLaunchKernelGGL(k_col_scalars, dim3(grid_for((int64_t)m->ncols * 64, 256, m->num_cus * 16)),
+                     dim3(256), 0, st, m->ncols, m->d_colptr, m->d_colind, m->d_colval,
+                     m->d_rowptr, m->d_csq, m->d_cnorm, d_cost);
+  HIP_TRY(hipGetLastError());
+  m->h_cost.resize((size_t)m->ncols);
+  HIP_TRY(hipMemcpyAsync(m->h_cost.data(), d_cost, sizeof(int64_t) * (size_t)m->ncols,
+                         hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipFree(d_cost));
+}
+
+void destroy(slimgpu_matrix* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  if (m->owns_csr) {
+    (void)hipFree(m->d_rowptr);
+    (void)hipFree(m->d_rowind);
+    (void)hipFree(m->d_rowval);
+  }
+  (void)hipFree(m->d_colptr);
+  (void)hipFree(m->d_colind);
+  (void)hipFree(m->d_colval);
+  (void)hipFree(m->d_cnorm);
+  (void)hipFree(m->d_csq);
+  for (slimgpu_matrix::Buf* b :
+       {&m->ws_order, &m->ws_cnt, &m->ws_off, &m->ws_stat_i, &m->ws_stat_l, &m->ws_stat_f,
+        &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_icolptr, &m->ws_icolind,
+        &m->ws_icolval})
+    if (b->p) (void)hipFree(b->p);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+}  // namespace
+
+slimgpu_stats_t& last_stats() { return g_stats; }
+ColumnStats& last_column_stats() { return g_colstats; }
+
+LearnOptions decode_options(const int32_t* io, const double* dopt) {
+  LearnOptions o;
+  auto geti = [&](int idx, int32_t def) { return (!io || io[idx] == -1) ? def : io[idx]; };
+  auto getd = [&](int idx, double def) { return (!dopt || dopt[idx] == -1) ? def : dopt[idx]; };
+  o.nthreads = geti(SLIM_OPTION_NTHREADS, 1);
+  o.nnbrs = geti(SLIM_OPTION_NNBRS, 0);
+  o.simtype = geti(SLIM_OPTION_SIMTYPE, SLIM_SIMTYPE_COS);
+  o.dbglvl = geti(SLIM_OPTION_DBGLVL, 0);
+  o.algo = geti(SLIM_OPTION_ALGO, SLIM_ALGO_CD);
+  o.ordered = geti(SLIM_OPTION_ORDERED, 0);
+  o.maxniters = geti(SLIM_OPTION_MAXNITERS, 10000);
+  o.l1r = getd(SLIM_OPTION_L1R, 1.0);
+  o.l2r = getd(SLIM_OPTION_L2R, 1.0);
+  o.optTol = getd(SLIM_OPTION_OPTTOL, 1e-7);
+  o.col_begin = geti(SLIM_OPTION_GPU_COLBEGIN, 0);
+  o.col_end = geti(SLIM_OPTION_GPU_COLEND, -1);
+  o.seed = (uint32_t)geti(SLIM_OPTION_GPU_SEED, 1);
+  o.device = geti(SLIM_OPTION_GPU_DEVICE, -1);
+  o.kernel = geti(SLIM_OPTION_GPU_KERNEL, SLIMGPU_KERNEL_AUTO);
+  return o;
+}
+
+int32_t device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+slimgpu_matrix_t* matrix_from_host(int32_t nrows, const ssize_t* rowptr, const int32_t* rowind,
+                                   const float* rowval, const LearnOptions& opt,
+                                   int32_t* status) {
+  if (nrows < 0 || !rowptr || (rowptr[nrows] > 0 && !rowind)) {
+    set_error("SLIMGPU_MatrixFromHost: bad CSR arguments");
+    if (status) *status = SLIM_ERROR_INPUT;
+    return nullptr;
+  }
+  auto* m = new slimgpu_matrix();
+  const double t0 = now_ms();
+  try {
+    pick_device(m, opt);
+    m->nrows = nrows;
+    m->nnz = rowptr[nrows];
+    m->binary = rowval == nullptr;
+    m->ncols = max_index_plus_one(m->nnz, rowind);  // setup.c:117
+    if (m->ncols <= 0) m->ncols = 1;
+    m->owns_csr = true;
+    m->d_rowptr = dev_alloc<int64_t>((size_t)nrows + 1);
+    m->d_rowind = dev_alloc<int32_t>((size_t)m->nnz);
+    m->d_rowval = m->binary ? nullptr : dev_alloc<float>((size_t)m->nnz);
+    static_assert(sizeof(ssize_t) == sizeof(int64_t), "LP64 expected");
+    HIP_TRY(hipMemcpyAsync(m->d_rowptr, rowptr, sizeof(int64_t) * ((size_t)nrows + 1),
+                           hipMemcpyHostToDevice, m->stream));
+    if (m->nnz > 0) {
+      HIP_TRY(hipMemcpyAsync(m->d_rowind, rowind, sizeof(int32_t) * (size_t)m->nnz,
+                             hipMemcpyHostToDevice, m->stream));
+      if (!m->binary)
+        HIP_TRY(hipMemcpyAsync(m->d_rowval, rowval, sizeof(float) * (size_t)m->nnz,
+                               hipMemcpyHostToDevice, m->stream));
+    }
+    build_column_view(m);
+    m->setup_ms = now_ms() - t0;
+    if (status) *status = SLIM_OK;
+    return m;
+  } catch (const HipError& e) {
+    report(e, "SLIMGPU_MatrixFromHost");
+    if (status) *status = status_of(e);
+    destroy(m);
+    return nullptr;
+  }
+}
+
+slimgpu_matrix_t* matrix_from_device(int32_t nrows, int32_t ncols, const int64_t* d_rowptr,
+                                     const int32_t* d_rowind, const float* d_rowval,
+                                     const LearnOptions& opt, int32_t* status) {
+  if (nrows < 0 || !d_rowptr) {
+    set_error("SLIMGPU_MatrixFromDevice: bad CSR arguments");
+    if (status) *status = SLIM_ERROR_INPUT;
+    return nullptr;
+  }
+  auto* m = new slimgpu_matrix();
+  const double t0 = now_ms();
+  try {
+    pick_device(m, opt);
+    m->nrows = nrows;
+    m->owns_csr = false;
+    m->d_rowptr = const_cast<int64_t*>(d_rowptr);
+    m->d_rowind = const_cast<int32_t*>(d_rowind);
+    m->d_rowval = const_cast<float*>(d_rowval);
+    m->binary = d_rowval == nullptr;
+    HIP_TRY(hipMemcpy(&m->nnz, d_rowptr + nrows, sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (ncols <= 0) {
+      int32_t* d_max = dev_alloc<int32_t>(1);
+      int32_t init = -1;
+      HIP_TRY(hipMemcpy(d_max, &init, sizeof(int32_t), hipMemcpyHostToDevice));
+      if (m->nnz > 0) {
+        hipLaunchKernelGGL(k_max_index, dim3(grid_for(m->nnz, 256, m->num_cus * 8)), dim3(256), 0,
+                           m->stream, m->d_rowind, m->nnz, d_max);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(m->stream));
+      }
+      HIP_TRY(hipMemcpy(&init, d_max, sizeof(int32_t), hipMemcpyDeviceToHost));
+      HIP_TRY(hipFree(d_max));
+      ncols = init + 1;
+    }
+    m->ncols = ncols > 0 ? ncols : 1;
+    build_column_view(m);
+    m->setup_ms = now_ms() - t0;
+    if (status) *status = SLIM_OK;
+    return m;
+  } catch (const HipError& e) {
+    report(e, "SLIMGPU_MatrixFromDevice");
+    if (status) *status = status_of(e);
+    destroy(m);
+    return nullptr;
+  }
+}
+
+void matrix_free(slimgpu_matrix_t* m) { destroy(m); }
+
+int32_t matrix_info(const slimgpu_matrix_t* m, int32_t* nrows, int32_t* ncols, int64_t* nnz) {
+  if (!m) return SLIM_ERROR_INPUT;
+  if (nrows) *nrows = m->nrows;
+  if (ncols) *ncols = m->ncols;
+  if (nnz) *nnz = m->nnz;
+  return SLIM_OK;
+}
+
+double matrix_setup_ms(const slimgpu_matrix_t* m) { return m ? m->setup_ms : 0.0; }
+
+int32_t matrix_get_column_view(const slimgpu_matrix_t* m, int64_t* colptr, int32_t* colind,
+                               float* colval, float* cnorms) {
+  if (!m) return SLIM_ERROR_INPUT;
+  try {
+    HIP_TRY(hipSetDevice(m->device));
+    if (colptr)
+      HIP_TRY(hipMemcpy(colptr, m->d_colptr, sizeof(int64_t) * ((size_t)m->ncols + 1),
+                        hipMemcpyDeviceToHost));
+    if (colind && m->nnz)
+      HIP_TRY(hipMemcpy(colind, m->d_colind, sizeof(int32_t) * (size_t)m->nnz,
+                        hipMemcpyDeviceToHost));
+    if (colval && m->nnz && m->d_colval)
+      HIP_TRY(hipMemcpy(colval, m->d_colval, sizeof(float) * (size_t)m->nnz,
+                        hipMemcpyDeviceToHost));
+    if (cnorms)
+      HIP_TRY(hipMemcpy(cnorms, m->d_cnorm, sizeof(float) * (size_t)m->ncols,
+                        hipMemcpyDeviceToHost));
+    return SLIM_OK;
+  } catch (const HipError& e) {
+    report(e, "SLIMGPU_MatrixGetColumnView");
+    return status_of(e);
+  }
+}
+
+// ---- the solve -----------------------------------------------------------------
+
+namespace {
+
+using KernelFn = void (*)(const DevMatrix, const SolveArgs);
+
+KernelFn pick_kernel(bool lds, bool has_val) {
+  if (lds) return has_val ? cd_wave_kernel<true, true> : cd_wave_kernel<true, false>;
+  return has_val ? cd_wave_kernel<false, true> : cd_wave_kernel<false, false>;
+}
+
+int round_up(int v, int q) { return (v + q - 1) / q * q; }
+
+}  // namespace
+
+slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
+                     int32_t* status) {
+  const double t_begin = now_ms();
+  slimgpu_stats_t st;
+  std::memset(&st, 0, sizeof(st));
+  auto fail = [&](int32_t code) -> slim_csr_t* {
+    if (status) *status = code;
+    return nullptr;
+  };
+  if (!m) {
+    set_error("SLIMGPU_Learn: null matrix");
+    return fail(SLIM_ERROR_INPUT);
+  }
+  const int32_t ncols = m->ncols;
+  int32_t cb = std::max(0, opt.col_begin);
+  int32_t ce = opt.col_end < 0 ? ncols : std::min(opt.col_end, ncols);
+  if (cb > ce) cb = ce;
+  const int32_t nwork = ce - cb;
+
+  try {
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t stream = m->stream;
+
+    // work list: most expensive columns first (longest-processing-time order)
+    std::vector<int32_t> order((size_t)nwork);
+    std::iota(order.begin(), order.end(), cb);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int32_t a, int32_t b) { return m->h_cost[a] > m->h_cost[b]; });
+
+    // kernel flavour and geometry
+    const int nrows_pad = round_up(std::max(m->nrows, 1), 64);
+    const int ncols_pad = round_up(ncols, 64);
+    const size_t vec_floats = (size_t)nrows_pad + 2 * (size_t)ncols_pad;
+    const size_t lds_need = vec_floats * sizeof(float);
+    bool use_lds;
+    if (opt.kernel == SLIMGPU_KERNEL_WAVE_LDS) {
+      if (lds_need > 160 * 1024) {
+        set_error("SLIMGPU_Learn: work vectors do not fit the 160 KiB LDS of a CU");
+        return fail(SLIM_ERROR_INPUT);
+      }
+      use_lds = true;
+    } else if (opt.kernel == SLIMGPU_KERNEL_WAVE_HBM) {
+      use_lds = false;
+    } else {
+      use_lds = lds_need <= 64 * 1024;
+    }
+    KernelFn fn = pick_kernel(use_lds, !m->binary);
+    int waves_per_cu;
+    if (use_lds) {
+      waves_per_cu = (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_need, 1));
+      if (waves_per_cu < 1) waves_per_cu = 1;
+      if (lds_need > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+    } else {
+      waves_per_cu = 8;
+    }
+    int nwaves = std::max(1, std::min(nwork, m->num_cus * waves_per_cu));
+
+    // device buffers
+    int32_t* d_order = ws_get<int32_t>(m->ws_order, (size_t)nwork);
+    int32_t* d_cnt = ws_get<int32_t>(m->ws_cnt, (size_t)ncols);
+    int64_t* d_off = ws_get<int64_t>(m->ws_off, (size_t)ncols);
+    int32_t* d_sti = ws_get<int32_t>(m->ws_stat_i, 3 * (size_t)ncols);
+    int64_t* d_stl = ws_get<int64_t>(m->ws_stat_l, 3 * (size_t)ncols);
+    float* d_stf = ws_get<float>(m->ws_stat_f, 2 * (size_t)ncols);
+    // misc: [0] queue (int32) [1] overflow (int32) [2..3] cursor (u64)
+    int32_t* d_misc = ws_get<int32_t>(m->ws_misc, 4);
+    float* d_slab = nullptr;
+    if (!use_lds) d_slab = ws_get<float>(m->ws_slab, vec_floats * (size_t)nwaves);
+
+    int64_t arena_cap = std::max<int64_t>(1 << 20, 2 * m->nnz);
+    const char* env_cap = std::getenv("SLIM_GPU_ARENA");
+    if (env_cap) arena_cap = std::max<int64_t>(1, std::atoll(env_cap));
+
+    // warm start: column view of imodel
+    const int64_t* d_icolptr = nullptr;
+    const int32_t* d_icolind = nullptr;
+    const float* d_icolval = nullptr;
+    int32_t incols = 0;
+    if (imodel && imodel->colptr && imodel->ncols > 0) {
+      incols = imodel->ncols;
+      const int64_t innz = imodel->colptr[incols];
+      int64_t* p = ws_get<int64_t>(m->ws_icolptr, (size_t)incols + 1);
+      int32_t* ci = ws_get<int32_t>(m->ws_icolind, (size_t)innz);
+      float* cv = ws_get<float>(m->ws_icolval, (size_t)innz);
+      HIP_TRY(hipMemcpyAsync(p, imodel->colptr, sizeof(int64_t) * ((size_t)incols + 1),
+                             hipMemcpyHostToDevice, stream));
+      if (innz > 0) {
+        HIP_TRY(hipMemcpyAsync(ci, imodel->colind, sizeof(int32_t) * (size_t)innz,
+                               hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(cv, imodel->colval, sizeof(float) * (size_t)innz,
+                               hipMemcpyHostToDevice, stream));
+      }
+      d_icolptr = p;
+      d_icolind = ci;
+      d_icolval = cv;
+    }
+
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (size_t)ncols, stream));
+    HIP_TRY(hipMemsetAsync(d_off, 0, sizeof(int64_t) * (size_t)ncols, stream));
+    HIP_TRY(hipMemsetAsync(d_sti, 0, sizeof(int32_t) * 3 * (size_t)ncols, stream));
+    HIP_TRY(hipMemsetAsync(d_stl, 0, sizeof(int64_t) * 3 * (size_t)ncols, stream));
+    HIP_TRY(hipMemsetAsync(d_stf, 0, sizeof(float) * 2 * (size_t)ncols, stream));
+
+    DevMatrix A;
+    A.nrows = m->nrows;
+    A.ncols = ncols;
+    A.nnz = m->nnz;
+    A.rowptr = m->d_rowptr;
+    A.rowind = m->d_rowind;
+    A.rowval = m->d_rowval;
+    A.colptr = m->d_colptr;
+    A.colind = m->d_colind;
+    A.colval = m->d_colval;
+    A.cnorm = m->d_cnorm;
+    A.csq = m->d_csq;
+
+    hipEvent_t ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+
+    std::vector<int32_t> h_cnt((size_t)ncols, 0);
+    std::vector<int64_t> h_off((size_t)ncols, 0);
+    std::vector<int32_t> h_ind;
+    std::vector<float> h_val;
+    std::vector<int32_t> pending = order;  // columns still to solve
+    double kernel_ms = 0;
+    // results per column (host), filled as launches complete
+    std::vector<int32_t> fin_cnt((size_t)ncols, 0);
+    std::vector<int64_t> fin_off((size_t)ncols, 0);
+    int64_t fin_total = 0;
+
+    for (int attempt = 0; attempt < 8 && !pending.empty(); ++attempt) {
+      const int32_t npend = (int32_t)pending.size();
+      int32_t* d_ai = ws_get<int32_t>(m->ws_arena_i, (size_t)arena_cap);
+      float* d_av = ws_get<float>(m->ws_arena_v, (size_t)arena_cap);
+      HIP_TRY(hipMemcpyAsync(d_order, pending.data(), sizeof(int32_t) * (size_t)npend,
+                             hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemsetAsync(d_misc, 0, sizeof(int32_t) * 4, stream));
+
+      SolveArgs S;
+      S.l1 = (float)opt.l1r;
+      S.l2 = (float)opt.l2r;
+      S.opt_tol = (float)opt.optTol;
+      S.maxniters = opt.maxniters;
+      S.seed = opt.seed;
+      S.order = d_order;
+      S.nwork = npend;
+      S.queue = d_misc;
+      S.icolptr = d_icolptr;
+      S.icolind = d_icolind;
+      S.icolval = d_icolval;
+      S.incols = incols;
+      S.slab = d_slab;
+      S.slab_stride = (int64_t)vec_floats;
+      S.nrows_pad = nrows_pad;
+      S.ncols_pad = ncols_pad;
+      S.out_cnt = d_cnt;
+      S.out_off = d_off;
+      S.out_ind = d_ai;
+      S.out_val = d_av;
+      S.out_cursor = reinterpret_cast<unsigned long long*>(d_misc + 2);
+      S.out_cap = arena_cap;
+      S.overflow = d_misc + 1;
+      S.st_na = d_sti;
+      S.st_sweeps = d_sti + ncols;
+      S.st_conv = d_sti + 2 * (size_t)ncols;
+      S.st_G = d_stl;
+      S.st_D = d_stl + ncols;
+      S.st_U = d_stl + 2 * (size_t)ncols;
+      S.st_err = d_stf;
+      S.st_obj = d_stf + ncols;
+
+      const int launch_waves = std::max(1, std::min(npend, nwaves));
+      HIP_TRY(hipEventRecord(ev0, stream));
+      hipLaunchKernelGGL(fn, dim3(launch_waves), dim3(64), use_lds ? lds_need : 0, stream, A, S);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(ev1, stream));
+
+      int32_t h_misc[4];
+      HIP_TRY(hipMemcpyAsync(h_misc, d_misc, sizeof(h_misc), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipMemcpyAsync(h_cnt.data(), d_cnt, sizeof(int32_t) * (size_t)ncols,
+                             hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipMemcpyAsync(h_off.data(), d_off, sizeof(int64_t) * (size_t)ncols,
+                             hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+      kernel_ms += ms;
+
+      unsigned long long cursor;
+      std::memcpy(&cursor, h_misc + 2, sizeof(cursor));
+      const int64_t used = std::min<int64_t>((int64_t)cursor, arena_cap);
+      const int64_t base = fin_total;
+      h_ind.resize((size_t)(base + used));
+      h_val.resize((size_t)(base + used));
+      if (used > 0) {
+        HIP_TRY(hipMemcpyAsync(h_ind.data() + base, d_ai, sizeof(int32_t) * (size_t)used,
+                               hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_val.data() + base, d_av, sizeof(float) * (size_t)used,
+                               hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+      }
+      fin_total += used;
+
+      std::vector<int32_t> again;
+      int64_t need = 0;
+      for (int32_t c : pending) {
+        if (h_cnt[c] >= 0) {
+          fin_cnt[c] = h_cnt[c];
+          fin_off[c] = base + h_off[c];
+        } else {  // did not fit the arena: solve again with a larger one
+          again.push_back(c);
+          need += -(int64_t)h_cnt[c] - 1;
+        }
+      }
+      pending.swap(again);
+      if (!pending.empty()) arena_cap = std::max<int64_t>(arena_cap, need + 1024);
+    }
+    HIP_TRY(hipEventDestroy(ev0));
+    HIP_TRY(hipEventDestroy(ev1));
+    if (!pending.empty()) {
+      set_error("SLIMGPU_Learn: output arena overflow persisted");
+      return fail(SLIM_ERROR_MEMORY);
+    }
+    const double t_kernel_done = now_ms();
+
+    // per-column counters
+    ColumnStats& cs = g_colstats;
+    cs.nacols.assign((size_t)ncols, 0);
+    cs.sweeps.assign((size_t)ncols, 0);
+    cs.conv.assign((size_t)ncols, 0);
+    cs.G.assign((size_t)ncols, 0);
+    cs.D.assign((size_t)ncols, 0);
+    cs.U.assign((size_t)ncols, 0);
+    std::vector<float> h_err((size_t)ncols), h_obj((size_t)ncols);
+    HIP_TRY(hipMemcpy(cs.nacols.data(), d_sti, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cs.sweeps.data(), d_sti + ncols, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cs.conv.data(), d_sti + 2 * (size_t)ncols, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cs.G.data(), d_stl, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cs.D.data(), d_stl + ncols, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cs.U.data(), d_stl + 2 * (size_t)ncols, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_err.data(), d_stf, sizeof(float) * (size_t)ncols, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_obj.data(), d_stf + ncols, sizeof(float) * (size_t)ncols, hipMemcpyDeviceToHost));
+
+    // SaveModel (estimate.c:570-593): concatenate the columns, then the row view
+    int64_t tnnz = 0;
+    for (int32_t c = 0; c < ncols; ++c) tnnz += fin_cnt[c];
+    auto* colptr = static_cast<ssize_t*>(std::malloc(sizeof(ssize_t) * ((size_t)ncols + 1)));
+    auto* colind = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(tnnz, 1)));
+    auto* colval = static_cast<float*>(std::malloc(sizeof(float) * (size_t)std::max<int64_t>(tnnz, 1)));
+    if (!colptr || !colind || !colval) {
+      std::free(colptr); std::free(colind); std::free(colval);
+      set_error("SLIMGPU_Learn: out of host memory for the model");
+      return fail(SLIM_ERROR_MEMORY);
+    }
+    colptr[0] = 0;
+    for (int32_t c = 0; c < ncols; ++c) {
+      const int64_t n = fin_cnt[c];
+      if (n > 0) {
+        std::memcpy(colind + colptr[c], h_ind.data() + fin_off[c], sizeof(int32_t) * (size_t)n);
+        std::memcpy(colval + colptr[c], h_val.data() + fin_off[c], sizeof(float) * (size_t)n);
+      }
+      colptr[c + 1] = colptr[c] + n;
+    }
+    slim_csr_t* model = model_from_columns(ncols, colptr, colind, colval);
+
+    st.ncols_solved = nwork;
+    st.kernel = use_lds ? SLIMGPU_KERNEL_WAVE_LDS : SLIMGPU_KERNEL_WAVE_HBM;
+    st.nwaves = nwaves;
+    st.lds_bytes = use_lds ? (int32_t)lds_need : 0;
+    st.setup_ms = m->setup_ms;
+    st.kernel_ms = kernel_ms;
+    for (int32_t c = cb; c < ce; ++c) {
+      st.G += cs.G[c];
+      st.D += cs.D[c];
+      st.U += cs.U[c];
+      st.sweeps += cs.sweeps[c];
+      st.error += h_err[c];
+      st.objval += h_obj[c];
+    }
+    st.nnzW = tnnz;
+    st.alg_bytes = m->binary
+                       ? 4.0 * st.G + 8.0 * st.D + 4.0 * st.U + 8.0 * st.nnzW
+                       : 8.0 * st.G + 12.0 * st.D + 4.0 * st.U + 8.0 * st.nnzW;
+    st.gather_ms = now_ms() - t_kernel_done;
+    st.total_ms = now_ms() - t_begin;
+    g_stats = st;
+    if (opt.dbglvl & SLIM_DBG_INFO)  // estimate.c:552-555
+      std::printf("Done estimation: loss: %.5le, fit: %.5le, ffrac: %.3lf,  #nzs: %zd\n", st.objval,
+                  st.error, st.objval != 0 ? st.error / st.objval : 0.0, (ssize_t)tnnz);
+    if (status) *status = SLIM_OK;
+    return model;
+  } catch (const HipError& e) {
+    report(e, "SLIMGPU_Learn");
+    return fail(status_of(e));
+  }
+}
+
+}  // namespace slimamd

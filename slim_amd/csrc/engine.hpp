@@ -1,0 +1,53 @@
+// engine.hpp -- device side of libslim.so: the training matrix staged in HBM and
+// the driver that runs the CD kernels over a set of item columns.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/slim_gpu.h"
+
+namespace slimamd {
+
+// Decoded SLIM_Learn options (reference src/libslim/api.c:42-52 + slim_gpu.h).
+struct LearnOptions {
+  int32_t nthreads = 1, nnbrs = 0, simtype = 0, dbglvl = 0, algo = SLIM_ALGO_CD;
+  int32_t ordered = 0, maxniters = 10000;
+  double l1r = 1.0, l2r = 1.0, optTol = 1e-7;
+  int32_t col_begin = 0, col_end = -1;  // -1: ncols
+  uint32_t seed = 1;
+  int32_t device = -1;  // -1: current
+  int32_t kernel = SLIMGPU_KERNEL_AUTO;
+};
+LearnOptions decode_options(const int32_t* ioptions, const double* doptions);
+
+struct ColumnStats {
+  std::vector<int32_t> nacols, sweeps, conv;
+  std::vector<int64_t> G, D, U;
+};
+
+// Per-thread record of the most recent solve (SLIMGPU_LastStats & co).
+slimgpu_stats_t& last_stats();
+ColumnStats& last_column_stats();
+
+// Implemented in engine.hip
+slimgpu_matrix_t* matrix_from_host(int32_t nrows, const ssize_t* rowptr,
+                                   const int32_t* rowind, const float* rowval,
+                                   const LearnOptions& opt, int32_t* status);
+slimgpu_matrix_t* matrix_from_device(int32_t nrows, int32_t ncols,
+                                     const int64_t* d_rowptr, const int32_t* d_rowind,
+                                     const float* d_rowval, const LearnOptions& opt,
+                                     int32_t* status);
+void matrix_free(slimgpu_matrix_t* m);
+int32_t matrix_info(const slimgpu_matrix_t* m, int32_t* nrows, int32_t* ncols, int64_t* nnz);
+int32_t matrix_get_column_view(const slimgpu_matrix_t* m, int64_t* colptr, int32_t* colind,
+                               float* colval, float* cnorms);
+double matrix_setup_ms(const slimgpu_matrix_t* m);
+
+// EstimateModelCD + SaveModel on the device matrix.  Returns a host model
+// (slim_csr_t with both views) or nullptr with *status set.
+slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
+                     int32_t* status);
+
+int32_t device_count();
+
+}  // namespace slimamd

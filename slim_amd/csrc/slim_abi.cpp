@@ -1,0 +1,393 @@
+// slim_abi.cpp -- every exported symbol of libslim.so (include/slim.h, slim_gpu.h).
+//
+// Thin C-ABI shim: decodes the option arrays, moves data between the caller's
+// buffers and the engine, never computes a CD update on the host.  SLIM_Learn /
+// Py_SLIM_Learn / Py_SLIM_Mselect reach the solver only through
+// slimamd::learn_cd (HIP, engine.hip); if no gfx950 device is usable they fail
+// with SLIM_ERROR* and a message -- there is no CPU fallback.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "engine.hpp"
+#include "host_csr.hpp"
+
+using namespace slimamd;
+
+namespace {
+
+slim_csr_t* as_csr(slim_t* h) { return static_cast<slim_csr_t*>(h); }
+
+// SLIM_Learn body shared by the C and Python entry points (the reference
+// duplicates it: src/libslim/api.c:36-95 == src/libslim/pyapi.c:136-198).
+slim_csr_t* learn_from_host(int32_t nrows, const ssize_t* rowptr, const int32_t* rowind,
+                            const float* rowval, int32_t* ioptions, double* doptions,
+                            const slim_csr_t* imodel, int32_t* status) {
+  set_error("");
+  LearnOptions opt = decode_options(ioptions, doptions);
+  if (opt.algo != SLIM_ALGO_CD) {
+    // reference: ADMM needs MKL and otherwise exits (estimate.c:309-317)
+    set_error("only algo=cd (coordinate descent) is implemented by this engine");
+    *status = SLIM_ERROR_INPUT;
+    return nullptr;
+  }
+  if (opt.nnbrs > 0) {
+    set_error("fSLIM (nnbrs > 0) is not implemented by this engine yet");
+    *status = SLIM_ERROR_INPUT;
+    return nullptr;
+  }
+  slimgpu_matrix_t* mat = matrix_from_host(nrows, rowptr, rowind, rowval, opt, status);
+  if (!mat) return nullptr;
+  slim_csr_t* model = learn_cd(mat, opt, imodel, status);
+  if (model && (opt.dbglvl & SLIM_DBG_TIME)) {  // timing.c:27-45
+    const slimgpu_stats_t& s = last_stats();
+    std::printf("\nTiming Information -------------------------------------------------");
+    std::printf("\n Total: \t %7.3lf", (s.setup_ms + s.total_ms) / 1e3);
+    std::printf("\n   Setup: \t\t %7.3lf", s.setup_ms / 1e3);
+    std::printf("\n   Learn: \t\t %7.3lf", s.total_ms / 1e3);
+    std::printf("\n     kernel: \t\t %7.3lf", s.kernel_ms / 1e3);
+    std::printf("\n********************************************************************\n");
+  }
+  matrix_free(mat);
+  return model;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- slim.h ------
+
+int32_t SLIM_iSetDefaults(int32_t* options) {
+  for (int i = 0; i < SLIM_NOPTIONS; ++i) options[i] = -1;
+  return SLIM_OK;
+}
+
+int32_t SLIM_dSetDefaults(double* options) {
+  for (int i = 0; i < SLIM_NOPTIONS; ++i) options[i] = -1;
+  return SLIM_OK;
+}
+
+slim_t* SLIM_Learn(int32_t nrows, ssize_t* rowptr, int32_t* rowind, float* rowval,
+                   int32_t* ioptions, double* doptions, slim_t* imodel, int32_t* r_status) {
+  int32_t status = SLIM_ERROR;
+  slim_csr_t* model =
+      learn_from_host(nrows, rowptr, rowind, rowval, ioptions, doptions, as_csr(imodel), &status);
+  if (r_status) *r_status = status;
+  return model;
+}
+
+int32_t SLIM_GetTopN(slim_t* model, int32_t nratings, int32_t* itemids, float* ratings,
+                     int32_t* /*ioptions*/, int32_t nrcmds, int32_t* rids, float* rscores) {
+  const slim_csr_t* W = as_csr(model);
+  if (!W || !W->rowptr || nrcmds < 0) return SLIM_ERROR;
+  TopNScratch ws(W->ncols > W->nrows ? W->ncols : W->nrows);
+  return top_n(W, nratings, itemids, ratings, nrcmds, rids, rscores, ws);
+}
+
+int32_t SLIM_WriteModel(slim_t* model, char* filename) {
+  const slim_csr_t* W = as_csr(model);
+  if (!W || !W->rowptr) return SLIM_ERROR_INPUT;
+  return write_binrow(W, filename) ? SLIM_OK : SLIM_ERROR;
+}
+
+slim_t* SLIM_ReadModel(char* filename) {
+  slim_csr_t* W = read_binrow(filename);
+  if (W) csr_build_index(W, 0);  // api.c:191: add the column view
+  return W;
+}
+
+void SLIM_FreeModel(slim_t** model) {
+  if (!model) return;
+  csr_free(as_csr(*model));
+  *model = nullptr;
+}
+
+int32_t* SLIM_DetermineHeadAndTail(int32_t nrows, int32_t ncols, ssize_t* rowptr,
+                                   int32_t* rowind) {
+  return head_tail_split(nrows, ncols, rowptr, rowind);
+}
+
+// ------------------------------------------------------------ Py_* (pyapi.c) --
+
+int32_t Py_csr_wrapper(int32_t nrows, ssize_t* rowptr, int32_t* rowind, float* rowval,
+                       slim_t** matrix_out) {
+  slim_csr_t* m = csr_from_rows(nrows, rowptr, rowind, rowval);
+  if (!m) return SLIM_ERROR_MEMORY;
+  *matrix_out = m;
+  return SLIM_OK;
+}
+
+int32_t Py_csr_save(slim_t* mathandle, char* fname) {
+  const slim_csr_t* m = as_csr(mathandle);
+  if (!m || !m->rowptr) return SLIM_ERROR_INPUT;
+  return write_text_csr(m, fname) ? SLIM_OK : SLIM_ERROR;
+}
+
+int32_t Py_csr_load(slim_t** mathandle, char* fname) {
+  slim_csr_t* m = read_text_csr(fname);
+  if (!m) return SLIM_ERROR;
+  *mathandle = m;
+  return SLIM_OK;
+}
+
+int32_t Py_csr_free(slim_t* mathandle) {
+  csr_free(as_csr(mathandle));
+  return SLIM_OK;
+}
+
+int32_t Py_csr_stat(slim_t* mathandle, int32_t* nnz) {
+  const slim_csr_t* m = as_csr(mathandle);
+  if (!m || !m->rowptr) return SLIM_ERROR_INPUT;
+  *nnz = (int32_t)m->rowptr[m->nrows];
+  return SLIM_OK;
+}
+
+int32_t Py_csr_export(slim_t* mathandle, int32_t* indptr, int32_t* indices, float* data) {
+  const slim_csr_t* m = as_csr(mathandle);
+  if (!m || !m->rowptr) return SLIM_ERROR_INPUT;
+  const ssize_t nnz = m->rowptr[m->nrows];
+  for (int32_t r = 0; r <= m->nrows; ++r) indptr[r] = (int32_t)m->rowptr[r];
+  for (ssize_t k = 0; k < nnz; ++k) indices[k] = m->rowind[k];
+  if (m->rowval)
+    for (ssize_t k = 0; k < nnz; ++k) data[k] = m->rowval[k];
+  return SLIM_OK;
+}
+
+int32_t Py_SLIM_Learn(slim_t* trnhandle, int32_t* ioptions, double* doptions,
+                      slim_t** model_out) {
+  const slim_csr_t* trn = as_csr(trnhandle);
+  if (!trn || !trn->rowptr) return SLIM_ERROR_INPUT;
+  int32_t status = SLIM_ERROR;
+  slim_csr_t* model = learn_from_host(trn->nrows, trn->rowptr, trn->rowind, trn->rowval, ioptions,
+                                      doptions, nullptr, &status);
+  if (!model) return status;
+  *model_out = model;
+  return SLIM_OK;
+}
+
+int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
+                        double* doptions, double* arrayl1, double* arrayl2, int32_t nl1,
+                        int32_t nl2, double* bestl1HR, double* bestl2HR, double* bestHRHR,
+                        double* bestARHR, double* bestl1AR, double* bestl2AR, double* bestHRAR,
+                        double* bestARAR) {
+  const slim_csr_t* trn = as_csr(trnhandle);
+  const slim_csr_t* tst = as_csr(tsthandle);
+  if (!trn || !tst || !trn->rowptr || !tst->rowptr) return SLIM_ERROR_INPUT;
+  set_error("");
+  LearnOptions base = decode_options(ioptions, doptions);
+  const int32_t nrcmds =
+      (!ioptions || ioptions[SLIM_OPTION_NRCMDS] == -1) ? 10 : ioptions[SLIM_OPTION_NRCMDS];
+  if (base.algo != SLIM_ALGO_CD || base.nnbrs > 0) {
+    set_error("Py_SLIM_Mselect: only algo=cd, nnbrs=0 is implemented by this engine");
+    return SLIM_ERROR_INPUT;
+  }
+
+  // R goes to HBM once for the whole grid (the reference re-runs
+  // CreateTrainingMatrix inside every SLIM_Learn call, pyapi.c:295-297)
+  int32_t status = SLIM_ERROR;
+  slimgpu_matrix_t* mat =
+      matrix_from_host(trn->nrows, trn->rowptr, trn->rowind, trn->rowval, base, &status);
+  if (!mat) return status;
+
+  const int32_t trn_ncols = max_index_plus_one(trn->rowptr[trn->nrows], trn->rowind);
+  const int32_t tst_ncols = max_index_plus_one(tst->rowptr[tst->nrows], tst->rowind);
+  const int32_t ncols = trn_ncols > tst_ncols ? trn_ncols : tst_ncols;  // pyapi.c:255-257
+  int32_t* fmarker = head_tail_split(trn->nrows, ncols, trn->rowptr, trn->rowind);
+
+  std::printf("------------------------------------------------------------------\n");
+  std::printf("SLIM, version %s (MI355X engine)\n", SLIM_VERSION);
+  std::printf("------------------------------------------------------------------\n");
+  std::printf("  trn matrix, nrows: %d, ncols: %d, nnz: %zd\n", trn->nrows, ncols,
+              trn->rowptr[trn->nrows]);
+  std::printf("  tst matrix, nrows: %d, ncols: %d, nnz: %zd\n", tst->nrows, tst_ncols,
+              tst->rowptr[tst->nrows]);
+  std::printf("  optTol: %.2le, niters: %d\n", base.optTol, base.maxniters);
+  std::printf("\nEstimating & evaluating models...\n\n");
+
+  *bestHRHR = *bestARHR = *bestHRAR = *bestARAR = 0.0;
+  slim_csr_t* model = nullptr;
+  int32_t rc = SLIM_OK;
+  for (int32_t a = 0; a < nl1 && rc == SLIM_OK; ++a) {
+    for (int32_t b = 0; b < nl2; ++b) {
+      doptions[SLIM_OPTION_L1R] = arrayl1[a];  // the reference writes these through
+      doptions[SLIM_OPTION_L2R] = arrayl2[b];  // to the caller's array (pyapi.c:288-289)
+      LearnOptions opt = base;
+      opt.l1r = arrayl1[a];
+      opt.l2r = arrayl2[b];
+      slim_csr_t* prev = model;  // warm start from the previous cell
+      model = learn_cd(mat, opt, prev, &status);
+      csr_free(prev);
+      if (!model) {
+        rc = status;
+        break;
+      }
+      const EvalResult ev = evaluate(model, trn, tst, nrcmds, fmarker, ncols);
+      std::printf("l1r: %.2le l2r: %.2le nnz: %7zd hr: %.4f hr_head: %.4f hr_tail: %.4f "
+                  "arhr: %.4f time: %.2lf\n",
+                  opt.l1r, opt.l2r, model->rowptr[model->nrows], ev.hr, ev.hr_head, ev.hr_tail,
+                  ev.arhr, last_stats().total_ms / 1e3);
+      if (ev.nvalid < 1) {  // pyapi.c:377-381
+        *bestl1HR = opt.l1r;
+        *bestl2HR = opt.l2r;
+        rc = SLIM_ERROR;
+        break;
+      }
+      if (ev.hr > *bestHRHR) {
+        *bestHRHR = ev.hr;
+        *bestARHR = ev.arhr;
+        *bestl1HR = opt.l1r;
+        *bestl2HR = opt.l2r;
+      }
+      if (ev.arhr > *bestARAR) {
+        *bestHRAR = ev.hr;
+        *bestARAR = ev.arhr;
+        *bestl1AR = opt.l1r;
+        *bestl2AR = opt.l2r;
+      }
+    }
+  }
+  std::printf("\nDone.\n------------------------------------------------------------------\n");
+  csr_free(model);
+  std::free(fmarker);
+  matrix_free(mat);
+  return rc;
+}
+
+int32_t Py_SLIM_GetTopN(slim_t* model, int32_t nratings, int32_t* itemids, float* ratings,
+                        int32_t nrcmds, int32_t* rids, float* rscores, int32_t /*dbglvl*/) {
+  return SLIM_GetTopN(model, nratings, itemids, ratings, nullptr, nrcmds, rids, rscores);
+}
+
+int32_t Py_SLIM_GetTopN_1vsk(slim_t* model, int32_t nratings, int32_t* itemids, float* ratings,
+                             int32_t nrcmds, int32_t* rids, float* rscores, int32_t nnegs,
+                             int32_t* negitems, int32_t /*dbglvl*/) {
+  const slim_csr_t* W = as_csr(model);
+  if (!W || !W->rowptr || nrcmds < 0 || nnegs < 0) return SLIM_ERROR;
+  return top_n_1vsk(W, nratings, itemids, ratings, nrcmds, rids, rscores, nnegs, negitems);
+}
+
+int32_t Py_SLIM_Predict(int32_t nrcmds, slim_t* slimhandle, slim_t* trnhandle, int32_t* output,
+                        float* scores) {
+  const slim_csr_t* W = as_csr(slimhandle);
+  const slim_csr_t* trn = as_csr(trnhandle);
+  if (!W || !trn || !W->rowptr || !trn->rowptr || nrcmds < 0) return SLIM_ERROR;
+  TopNScratch ws(W->ncols > W->nrows ? W->ncols : W->nrows);
+  std::vector<int32_t> rids(nrcmds);
+  std::vector<float> rsc(nrcmds);
+  for (int32_t u = 0; u < trn->nrows; ++u) {
+    const ssize_t lo = trn->rowptr[u], hi = trn->rowptr[u + 1];
+    const int32_t n = top_n(W, (int32_t)(hi - lo), trn->rowind + lo,
+                            trn->rowval ? trn->rowval + lo : nullptr, nrcmds, rids.data(),
+                            rsc.data(), ws);
+    for (int32_t r = 0; r < n; ++r) {
+      output[(ssize_t)u * nrcmds + r] = rids[r];
+      scores[(ssize_t)u * nrcmds + r] = rsc[r];
+    }
+  }
+  return trn->nrows > 0 ? SLIM_OK : SLIM_ERROR;  // nvalid < 1 => error (pyapi.c:558-562)
+}
+
+int32_t Py_SLIM_Predict_1vsk(int32_t nrcmds, int32_t nnegs, slim_t* slimhandle,
+                             slim_t* trnhandle, int32_t* negitems, int32_t* output,
+                             float* scores) {
+  const slim_csr_t* W = as_csr(slimhandle);
+  const slim_csr_t* trn = as_csr(trnhandle);
+  if (!W || !trn || !W->rowptr || !trn->rowptr || nrcmds < 0 || nnegs < 0) return SLIM_ERROR;
+  std::vector<int32_t> rids(nrcmds);
+  std::vector<float> rsc(nrcmds);
+  for (int32_t u = 0; u < trn->nrows; ++u) {
+    const ssize_t lo = trn->rowptr[u], hi = trn->rowptr[u + 1];
+    const int32_t n = top_n_1vsk(W, (int32_t)(hi - lo), trn->rowind + lo,
+                                 trn->rowval ? trn->rowval + lo : nullptr, nrcmds, rids.data(),
+                                 rsc.data(), nnegs, negitems + (ssize_t)u * nnegs);
+    for (int32_t r = 0; r < n; ++r) {
+      output[(ssize_t)u * nrcmds + r] = rids[r];
+      scores[(ssize_t)u * nrcmds + r] = rsc[r];
+    }
+  }
+  return trn->nrows > 0 ? SLIM_OK : SLIM_ERROR;
+}
+
+// ------------------------------------------------------------- SLIMGPU_* ------
+
+slimgpu_matrix_t* SLIMGPU_MatrixFromHost(int32_t nrows, const ssize_t* rowptr,
+                                         const int32_t* rowind, const float* rowval,
+                                         int32_t* ioptions, int32_t* r_status) {
+  set_error("");
+  int32_t status = SLIM_ERROR;
+  slimgpu_matrix_t* m =
+      matrix_from_host(nrows, rowptr, rowind, rowval, decode_options(ioptions, nullptr), &status);
+  if (r_status) *r_status = status;
+  return m;
+}
+
+slimgpu_matrix_t* SLIMGPU_MatrixFromDevice(int32_t nrows, int32_t ncols, const int64_t* d_rowptr,
+                                           const int32_t* d_rowind, const float* d_rowval,
+                                           int32_t* ioptions, int32_t* r_status) {
+  set_error("");
+  int32_t status = SLIM_ERROR;
+  slimgpu_matrix_t* m = matrix_from_device(nrows, ncols, d_rowptr, d_rowind, d_rowval,
+                                           decode_options(ioptions, nullptr), &status);
+  if (r_status) *r_status = status;
+  return m;
+}
+
+void SLIMGPU_MatrixFree(slimgpu_matrix_t** mat) {
+  if (!mat) return;
+  matrix_free(*mat);
+  *mat = nullptr;
+}
+
+int32_t SLIMGPU_MatrixInfo(const slimgpu_matrix_t* mat, int32_t* nrows, int32_t* ncols,
+                           int64_t* nnz) {
+  return matrix_info(mat, nrows, ncols, nnz);
+}
+
+int32_t SLIMGPU_MatrixGetColumnView(const slimgpu_matrix_t* mat, int64_t* colptr,
+                                    int32_t* colind, float* colval, float* cnorms) {
+  return matrix_get_column_view(mat, colptr, colind, colval, cnorms);
+}
+
+slim_t* SLIMGPU_Learn(slimgpu_matrix_t* mat, int32_t* ioptions, double* doptions, slim_t* imodel,
+                      int32_t* r_status) {
+  set_error("");
+  int32_t status = SLIM_ERROR;
+  LearnOptions opt = decode_options(ioptions, doptions);
+  slim_csr_t* model = nullptr;
+  if (opt.algo != SLIM_ALGO_CD || opt.nnbrs > 0) {
+    set_error("SLIMGPU_Learn: only algo=cd, nnbrs=0 is implemented");
+    status = SLIM_ERROR_INPUT;
+  } else {
+    model = learn_cd(mat, opt, as_csr(imodel), &status);
+  }
+  if (r_status) *r_status = status;
+  return model;
+}
+
+int32_t SLIMGPU_LastStats(slimgpu_stats_t* out) {
+  if (!out) return SLIM_ERROR_INPUT;
+  *out = last_stats();
+  return SLIM_OK;
+}
+
+int32_t SLIMGPU_LastColumnStats(int32_t ncols, int32_t* nacols, int32_t* sweeps, int32_t* conv,
+                                int64_t* G, int64_t* D, int64_t* U) {
+  const ColumnStats& cs = last_column_stats();
+  if ((size_t)ncols > cs.nacols.size()) return SLIM_ERROR_INPUT;
+  const size_t n = (size_t)ncols;
+  if (nacols) std::memcpy(nacols, cs.nacols.data(), sizeof(int32_t) * n);
+  if (sweeps) std::memcpy(sweeps, cs.sweeps.data(), sizeof(int32_t) * n);
+  if (conv) std::memcpy(conv, cs.conv.data(), sizeof(int32_t) * n);
+  if (G) std::memcpy(G, cs.G.data(), sizeof(int64_t) * n);
+  if (D) std::memcpy(D, cs.D.data(), sizeof(int64_t) * n);
+  if (U) std::memcpy(U, cs.U.data(), sizeof(int64_t) * n);
+  return SLIM_OK;
+}
+
+int32_t SLIMGPU_DeviceCount(void) { return device_count(); }
+
+const char* SLIMGPU_LastError(void) { return last_error(); }
+
+}  // extern "C"
