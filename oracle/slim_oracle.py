@@ -173,3 +173,26 @@ def perm_key(seed, item, sweep):
 
 def max_threads():
     return int(lib().oracle_max_threads())
+
+
+def head_tail(trn, ncols):
+    """SLIM_DetermineHeadAndTail restated (api.c:215-245): 0 = head, 1 = tail."""
+    nu, tp, ti, _ = _csr_arrays(trn, True)
+    fm = np.zeros(ncols, dtype=np.int32)
+    lib().oracle_head_tail(C.c_int32(nu), C.c_int32(ncols), _p(tp, C.c_int64), _p(ti, C.c_int32),
+                           _p(fm, C.c_int32))
+    return fm
+
+
+def get_topn(W, itemids, ratings=None, nrcmds=10):
+    ncols, wp, wi, wv = _w_rows(W)
+    ids = np.ascontiguousarray(itemids, dtype=np.int32)
+    rt = None if ratings is None else np.ascontiguousarray(ratings, dtype=np.float32)
+    rids = np.zeros(nrcmds, np.int32)
+    rsc = np.zeros(nrcmds, np.float32)
+    lib().oracle_get_topn.restype = C.c_int32
+    n = lib().oracle_get_topn(C.c_int32(ncols), _p(wp, C.c_int64), _p(wi, C.c_int32),
+                              _p(wv, C.c_float), C.c_int32(ids.size), _p(ids, C.c_int32),
+                              _p(rt, C.c_float), C.c_int32(nrcmds), _p(rids, C.c_int32),
+                              _p(rsc, C.c_float))
+    return rids[:n], rsc[:n]

@@ -1,0 +1,82 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def has_gpu():
+    try:
+        from slim_amd import _lib
+        return _lib.load().SLIMGPU_DeviceCount() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Tests run against the in-tree libslim.so and the compiled oracle; build both if
+    a fresh checkout lacks them (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    so = os.path.join(ROOT, "slim_amd", "libslim.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "slim_amd", "csrc")])
+    import slim_oracle
+    slim_oracle.build()
+
+
+@pytest.fixture(scope="session")
+def ml100k():
+    from slim_amd.io import read_csr_text
+    R = read_csr_text(os.path.join(GOLDEN, "ml100k-train.csr"))
+    T = read_csr_text(os.path.join(GOLDEN, "ml100k-test.csr"), nrows=R.shape[0])
+    return R, T
+
+
+@pytest.fixture(scope="session")
+def automotive_triplets():
+    from slim_amd.io import read_ijv
+    trn = read_ijv(os.path.join(GOLDEN, "AutomotiveTrain.ijv"))
+    tst = read_ijv(os.path.join(GOLDEN, "AutomotiveTest.ijv"))
+    return trn, tst
+
+
+def map_triplets(trn, tst):
+    """The reference wrapper's id mapping (python-package/SLIM/core.py:289-351) done
+    with plain numpy: dense ids in first-appearance order; test events outside the
+    training maps are dropped."""
+    import scipy.sparse as sp
+
+    def first_seen(keys):
+        table, names = {}, []
+        for k in keys:
+            if k not in table:
+                table[k] = len(names)
+                names.append(k)
+        return table, names
+
+    u2i, users = first_seen(trn[:, 0])
+    i2i, items = first_seen(trn[:, 1])
+    R = sp.csr_matrix((trn[:, 2], ([u2i[u] for u in trn[:, 0]], [i2i[i] for i in trn[:, 1]])),
+                      shape=(len(users), len(items)))
+    keep = [(u2i[u], i2i[i], v) for u, i, v in tst if u in u2i and i in i2i]
+    keep = np.array(keep)
+    T = sp.csr_matrix((keep[:, 2], (keep[:, 0].astype(int), keep[:, 1].astype(int))),
+                      shape=R.shape)
+    return R, T, np.array(users), np.array(items)
+
+
+@pytest.fixture(scope="session")
+def automotive(automotive_triplets):
+    return map_triplets(*automotive_triplets)

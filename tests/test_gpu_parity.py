@@ -1,0 +1,295 @@
+"""Parity of the HIP solver (through the C ABI of libslim.so) with the CPU oracle.
+
+Tolerances (fp32 engine vs fp64 reference arithmetic; BASELINE.md 2 for the
+reference's own run-to-run noise):
+  * same visiting order as the oracle, default optTol 1e-7:   max|dW| <= 2e-5
+  * reference order (libc rand()) vs engine order, optTol 1e-7: max|dW| <= 3e-3
+    (the reference differs from itself by 1.7e-3 when only the seed changes)
+  * tight tolerance (optTol 1e-12): max|dW| <= 2e-5 and identical top-10 lists
+  * HR@10 / ARHR on ml100k: equal to the reference's 0.3191 / 0.1504 (4 decimals)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import slim_oracle as O
+from slim_amd import SLIM, SLIMatrix, _lib
+from slim_amd.constants import SLIM_NOPTIONS, SLIM_OK, Opt
+from slim_amd.engine import (KERNEL_WAVE_HBM, KERNEL_WAVE_LDS, DeviceMatrix, model_to_scipy)
+
+pytestmark = pytest.mark.gpu
+
+
+def maxdiff(a, b):
+    d = abs(sp.csc_matrix(a) - sp.csc_matrix(b))
+    return float(d.max()) if d.nnz else 0.0
+
+
+def pattern_diff(a, b):
+    pa = sp.csc_matrix(a).copy()
+    pb = sp.csc_matrix(b).copy()
+    pa.data[:] = 1
+    pb.data[:] = 1
+    return int(abs(pa - pb).sum())
+
+
+@pytest.fixture(scope="module")
+def ml_dev(ml100k):
+    m = DeviceMatrix.from_scipy(ml100k[0])
+    yield m
+    m.close()
+
+
+# ---- staging: CreateTrainingMatrix on the device --------------------------------------------
+def _check_column_view(R, binary=False):
+    m = DeviceMatrix.from_scipy(R, binary=binary)
+    cp, ci, cv, cn = m.column_view()
+    Rc = sp.csr_matrix(R).tocsc()
+    Rc.sort_indices()
+    ncols = int(R.indices.max()) + 1 if R.nnz else 1
+    assert m.ncols == ncols and m.nrows == R.shape[0] and m.nnz == R.nnz
+    assert np.array_equal(cp[:Rc.shape[1] + 1][:ncols + 1], Rc.indptr[:ncols + 1])
+    assert np.array_equal(ci, Rc.indices)
+    if not binary:
+        assert np.array_equal(cv, Rc.data.astype(np.float32))
+        want = np.sqrt(np.asarray(Rc.multiply(Rc).sum(axis=0)).ravel()[:ncols])
+    else:
+        want = np.sqrt(np.diff(Rc.indptr)[:ncols])
+    assert np.allclose(cn, want, rtol=2e-7, atol=0)
+    m.close()
+
+
+def test_column_view_ml100k(ml100k):
+    _check_column_view(ml100k[0])
+    _check_column_view(ml100k[0], binary=True)
+
+
+def test_column_view_ragged(automotive):
+    _check_column_view(automotive[0])
+    rng = np.random.default_rng(5)
+    R = sp.random(300, 70, density=0.05, format="csr", random_state=rng, dtype=np.float32)
+    R.data = rng.integers(1, 6, R.nnz).astype(np.float32)
+    R = sp.vstack([sp.csr_matrix((3, 70), dtype=np.float32), R,
+                   sp.csr_matrix((2, 70), dtype=np.float32)]).tocsr()  # empty rows at both ends
+    _check_column_view(R)
+
+
+# ---- C2: ml100k ---------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ml_gpu(ml_dev):
+    W, st = ml_dev.learn(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=1)
+    return W, st, ml_dev.column_stats()
+
+
+def test_ml100k_same_order_as_oracle(ml100k, ml_gpu):
+    R, T = ml100k
+    W, st, cs = ml_gpu
+    Wo, so, err, obj = O.learn_cd(R, order=O.ORDER_PERM, seed=1, aty=O.ATY_GRAM, nthreads=8,
+                                  return_stats=True)
+    assert maxdiff(W, Wo) <= 2e-5
+    assert pattern_diff(W, Wo) <= 8
+    assert np.array_equal(cs.nacols, so["nacols"])          # identical active sets
+    assert np.array_equal(cs.G, so["G"])
+    assert (cs.sweeps == so["sweeps"]).mean() >= 0.99       # same stopping sweep
+    assert abs(cs.D.sum() - so["D"].sum()) <= 0.01 * so["D"].sum()
+    assert abs(st["objval"] - obj) <= 1e-4 * obj and abs(st["error"] - err) <= 1e-4 * err
+    assert st["alg_bytes"] == 8.0 * st["G"] + 12.0 * st["D"] + 4.0 * st["U"] + 8.0 * st["nnzW"]
+    assert st["nnzW"] == W.nnz and st["G"] == cs.G.sum()
+
+
+def test_ml100k_vs_reference_order_and_hr(ml100k, ml_gpu):
+    R, T = ml100k
+    W, st, _ = ml_gpu
+    Wref = O.learn_cd(R, order=O.ORDER_GLIBC, srand=1, aty=O.ATY_FULLSCAN)  # the pinned run
+    assert Wref.nnz == 65928
+    assert maxdiff(W, Wref) <= 3e-3
+    assert abs(W.nnz - Wref.nnz) <= 60
+    ev = O.evaluate(W, R, T)
+    assert ev["nvalid"] == 934
+    assert "%.4f" % ev["hr"] == "0.3191" and "%.4f" % ev["arhr"] == "0.1504"
+    assert "%.5e" % st["objval"] == "2.29460e+04" and "%.5e" % st["error"] == "2.06490e+04"
+
+
+def test_ml100k_tight_tolerance_identical_rankings(ml100k, ml_dev):
+    R, T = ml100k
+    W, st = ml_dev.learn(optTol=1e-12, niters=100000, seed=1)
+    Wref = O.learn_cd(R, order=O.ORDER_GLIBC, srand=1, aty=O.ATY_GRAM, optTol=1e-12,
+                      maxniters=100000, nthreads=8)
+    assert maxdiff(W, Wref) <= 2e-5
+    ids_g, sc_g = O.predict(W, R, 10)
+    ids_r, sc_r = O.predict(Wref, R, 10)
+    assert np.array_equal(ids_g, ids_r)  # all 934 top-10 lists identical, in order
+    assert np.abs(sc_g - sc_r).max() <= 1e-4
+
+
+def test_ml100k_kkt_conditions(ml100k, ml_dev):
+    """Optimality of the elastic-net NNLS (no oracle involved): for x_i > 0 the gradient
+    a_i.(y - Ax) - l2 x_i equals l1; for x_i = 0 it is <= l1."""
+    R, _ = ml100k
+    W, _ = ml_dev.learn(optTol=1e-12, niters=100000, seed=4)
+    A = np.asarray(R.todense(), dtype=np.float64)
+    X = np.asarray(W.todense(), dtype=np.float64)
+    assert np.all(np.diag(X) == 0) and X.min() >= 0
+    grad = A.T @ (A - A @ X)            # [i, iC] = a_i . (y_iC - A x_iC)
+    pos = X > 0
+    assert np.abs((grad - X)[pos] - 1.0).max() <= 2e-3     # l1 = l2 = 1
+    off = ~pos
+    np.fill_diagonal(off, False)
+    assert (grad[off] <= 1.0 + 2e-3).all()
+
+
+def test_kernels_and_shards_agree(ml100k, ml_dev, ml_gpu):
+    W, _, _ = ml_gpu
+    W_hbm, st = ml_dev.learn(seed=1, kernel=KERNEL_WAVE_HBM)
+    assert st["kernel"] == KERNEL_WAVE_HBM
+    assert maxdiff(W, W_hbm) == 0.0
+    parts = [ml_dev.learn(seed=1, col_begin=b, col_end=e)[0]
+             for b, e in ((0, 500), (500, 501), (501, 1683))]
+    for (b, e), P in zip(((0, 500), (500, 501), (501, 1683)), parts):
+        mask = np.zeros(1683, bool)
+        mask[b:e] = True
+        assert P[:, ~mask].nnz == 0
+    assert maxdiff(parts[0] + parts[1] + parts[2], W) == 0.0
+    empty, st = ml_dev.learn(col_begin=7, col_end=7)
+    assert empty.nnz == 0 and st["ncols_solved"] == 0
+
+
+def test_binary_matrix_path(ml100k, ml_gpu):
+    R, _ = ml100k
+    m = DeviceMatrix.from_scipy(R, binary=True)  # rowval == NULL (setup.c:122-126)
+    W, st = m.learn(seed=1)
+    assert maxdiff(W, ml_gpu[0]) == 0.0          # ml100k values are all 1.0
+    assert st["alg_bytes"] == 4.0 * st["G"] + 8.0 * st["D"] + 4.0 * st["U"] + 8.0 * st["nnzW"]
+    m.close()
+
+
+def test_warm_start(ml100k, ml_dev):
+    R, _ = ml100k
+    first, _ = ml_dev.learn(l1r=2.0, l2r=1.0, seed=1)
+    W, _ = ml_dev.learn(l1r=1.0, l2r=0.5, seed=2, imodel=first)
+    f_o = O.learn_cd(R, l1r=2.0, l2r=1.0, order=O.ORDER_PERM, seed=1, aty=O.ATY_GRAM, nthreads=8)
+    Wo = O.learn_cd(R, l1r=1.0, l2r=0.5, order=O.ORDER_PERM, seed=2, aty=O.ATY_GRAM, nthreads=8,
+                    imodel=f_o)
+    assert maxdiff(first, f_o) <= 2e-5
+    assert maxdiff(W, Wo) <= 1e-4
+    cold, _ = ml_dev.learn(l1r=1.0, l2r=0.5, seed=2)
+    st_w = ml_dev.learn(l1r=1.0, l2r=0.5, seed=2, imodel=first)[1]
+    st_c = ml_dev.learn(l1r=1.0, l2r=0.5, seed=2)[1]
+    assert st_w["sweeps"] < st_c["sweeps"]      # the point of warm starting
+    assert maxdiff(W, cold) <= 3e-3
+
+
+def test_c_api_slim_learn(ml100k, ml_gpu):
+    """The slim.h entry point itself: host CSR in, model handle out."""
+    lib = _lib.load()
+    R, _ = ml100k
+    io = np.full(SLIM_NOPTIONS, -1, np.int32)
+    do = np.full(SLIM_NOPTIONS, -1.0)
+    st = C.c_int32(0)
+    val = np.ascontiguousarray(R.data, np.float32)
+    h = lib.SLIM_Learn(R.shape[0], np.ascontiguousarray(R.indptr, np.intp),
+                       np.ascontiguousarray(R.indices, np.int32), val.ctypes.data_as(C.c_void_p),
+                       io.ctypes.data_as(C.c_void_p), do.ctypes.data_as(C.c_void_p), None,
+                       C.byref(st))
+    assert h and st.value == SLIM_OK
+    view = C.cast(h, C.POINTER(_lib.CsrView)).contents
+    assert view.nrows == 1683 and view.ncols == 1683 and view.rowptr and view.colptr
+    W = model_to_scipy(lib, h)
+    assert maxdiff(W, ml_gpu[0]) == 0.0   # defaults == l1 1, l2 1, optTol 1e-7, 10000, seed 1
+
+
+# ---- C3: Automotive through the Python API ------------------------------------------------------
+def test_automotive_python_api(automotive_triplets, automotive, capsys):
+    trn, tst = automotive_triplets
+    R, T, users, items = automotive
+    trainmat = SLIMatrix(trn)
+    model = SLIM()
+    model.train({"algo": "cd", "nthreads": 2, "l1r": 1.0, "l2r": 1.0, "gpu_seed": 1}, trainmat)
+    assert "Learning takes" in capsys.readouterr().out
+    W = model.to_csr()
+    Wo = O.learn_cd(R, maxniters=50, order=O.ORDER_PERM, seed=1, aty=O.ATY_GRAM, nthreads=8)
+    assert W.shape == (1835, 1835)
+    assert maxdiff(W, Wo) <= 5e-5
+    out, scores = model.predict(trainmat, nrcmds=10, returnscores=True)
+    ids, sc = O.predict(sp.csc_matrix(W), R, 10)
+    for u_raw, row in list(trainmat.user2id.items())[:200]:
+        filled = ids[row] >= 0
+        assert np.array_equal(out[u_raw][filled], items[ids[row][filled]])
+        assert np.allclose(scores[u_raw], sc[row], atol=1e-5)
+    # the notebook's setting (UserGuide.ipynb:146-158): niters 100
+    model.train({"algo": "cd", "nthreads": 1, "l1r": 1.0, "l2r": 1.0, "optTol": 1e-7,
+                 "niters": 100}, trainmat)
+    W100 = model.to_csr()
+    assert abs(W100.nnz - 84323) <= 40                      # reference probe: 84 323
+    assert abs(W100.data.astype(np.float64).sum() - 5220.359019) <= 0.05
+
+
+def test_automotive_mselect_reproduces_notebook(automotive_triplets, capsys):
+    """UserGuide.ipynb:262-277 run on the GPU engine through the same Python calls."""
+    trn, tst = automotive_triplets
+    trainmat = SLIMatrix(trn)
+    valmat = SLIMatrix(tst, trainmat)
+    params = {"dbglvl": 0, "algo": "cd", "nthreads": 1, "l1r": 1.0, "l2r": 1.0, "optTol": 1e-7,
+              "niters": 100}
+    model = SLIM()
+    model.mselect(params, trainmat, valmat, [0.01, 0.1, 0.5, 1, 2, 4, 5, 10, 20],
+                  [0.1, 0.5, 1, 2, 5, 10, 20, 30, 50], nrcmds=10)
+    text = capsys.readouterr().out
+    assert "The best HR is achieved by, l1: 20.0000, l2:0.1000, HR:0.1404, AR:0.0654." in text
+    assert "The best AR is achieved by, l1: 20.0000, l2:50.0000, HR:0.1390, AR:0.0669." in text
+
+
+# ---- shapes the reference's data do not cover -------------------------------------------------
+def _random_ratings(nu, ni, density, seed):
+    rng = np.random.default_rng(seed)
+    R = sp.random(nu, ni, density=density, format="csr", random_state=rng, dtype=np.float32)
+    R.data = rng.integers(1, 6, R.nnz).astype(np.float32)
+    R.sort_indices()
+    return R
+
+
+@pytest.mark.parametrize("kernel", [KERNEL_WAVE_LDS, KERNEL_WAVE_HBM])
+def test_random_ratings(kernel):
+    R = _random_ratings(3000, 400, 0.03, 11)
+    m = DeviceMatrix.from_scipy(R)
+    W, st = m.learn(l1r=2.0, l2r=3.0, seed=9, kernel=kernel)
+    Wo, so, err, obj = O.learn_cd(R, l1r=2.0, l2r=3.0, order=O.ORDER_PERM, seed=9, aty=O.ATY_GRAM,
+                                  nthreads=8, return_stats=True)
+    assert W.nnz > 1000
+    assert maxdiff(W, Wo) <= 5e-5
+    assert abs(st["objval"] - obj) <= 1e-4 * obj
+    m.close()
+
+
+def test_large_rows_use_hbm_kernel_automatically():
+    R = _random_ratings(40000, 150, 0.01, 3)   # 4*(40000+300) > 64 KiB of work vectors
+    m = DeviceMatrix.from_scipy(R)
+    W, st = m.learn(l1r=1.0, l2r=1.0, seed=2)
+    assert st["kernel"] == KERNEL_WAVE_HBM and st["lds_bytes"] == 0
+    Wo = O.learn_cd(R, order=O.ORDER_PERM, seed=2, aty=O.ATY_GRAM, nthreads=8)
+    assert maxdiff(W, Wo) <= 5e-5
+    m.close()
+
+
+def test_edge_cases():
+    # empty columns, an empty first column, single-user columns, maxniters 1, huge l1
+    rows = [0, 0, 1, 1, 2, 3, 3, 3]
+    cols = [1, 3, 1, 5, 3, 1, 3, 5]
+    R = sp.csr_matrix((np.ones(8, np.float32), (rows, cols)), shape=(5, 6))  # row 4 empty
+    m = DeviceMatrix.from_scipy(R)
+    assert m.ncols == 6
+    for kw in (dict(), dict(niters=1), dict(l1r=0.0, l2r=0.1), dict(l1r=100.0)):
+        W, _ = m.learn(seed=1, **kw)
+        Wo = O.learn_cd(R, order=O.ORDER_PERM, seed=1, aty=O.ATY_GRAM,
+                        l1r=kw.get("l1r", 1.0), l2r=kw.get("l2r", 1.0),
+                        maxniters=kw.get("niters", 10000))
+        assert W.shape == (6, 6) and maxdiff(W, Wo) <= 1e-5
+    assert m.learn(l1r=100.0)[0].nnz == 0
+    m.close()
+    # a matrix with no ratings at all
+    Z = sp.csr_matrix((4, 3), dtype=np.float32)
+    mz = DeviceMatrix.from_scipy(Z)
+    assert mz.learn()[0].nnz == 0
+    mz.close()
