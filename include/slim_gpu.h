@@ -137,6 +137,10 @@ int32_t SLIMGPU_MatrixGetColumnView(const slimgpu_matrix_t *mat, int64_t *colptr
                                     int32_t *colind, float *colval,
                                     float *cnorms);
 
+/* Scheduling cost proxy per item column (the Gram work G = sum over the column's
+ * users of nnz(row u)); multi-GPU drivers balance their column blocks with it. */
+int32_t SLIMGPU_MatrixColumnCost(const slimgpu_matrix_t *mat, int64_t *cost);
+
 /* The estimate step of SLIM_Learn (EstimateModelCD + SaveModel,
  * src/libslim/estimate.c:328-593) on a staged matrix.  Same options, imodel and
  * result conventions as SLIM_Learn; can be called repeatedly on one matrix

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "SLIMGPU_MatrixInfo": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_int64)]),
     "SLIMGPU_MatrixGetColumnView": (C.c_int32, [C.c_void_p] * 5),
+    "SLIMGPU_MatrixColumnCost": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "SLIMGPU_Learn": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_int32)]),
     "SLIMGPU_LastStats": (C.c_int32, [C.POINTER(Stats)]),

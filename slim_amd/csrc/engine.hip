@@ -423,6 +423,12 @@ int32_t matrix_info(const slimgpu_matrix_t* m, int32_t* nrows, int32_t* ncols, i
 
 double matrix_setup_ms(const slimgpu_matrix_t* m) { return m ? m->setup_ms : 0.0; }
 
+int32_t matrix_column_cost(const slimgpu_matrix_t* m, int64_t* cost) {
+  if (!m || !cost) return SLIM_ERROR_INPUT;
+  std::memcpy(cost, m->h_cost.data(), sizeof(int64_t) * m->h_cost.size());
+  return SLIM_OK;
+}
+
 int32_t matrix_get_column_view(const slimgpu_matrix_t* m, int64_t* colptr, int32_t* colind,
                                float* colval, float* cnorms) {
   if (!m) return SLIM_ERROR_INPUT;

@@ -42,6 +42,7 @@ int32_t matrix_info(const slimgpu_matrix_t* m, int32_t* nrows, int32_t* ncols, i
 int32_t matrix_get_column_view(const slimgpu_matrix_t* m, int64_t* colptr, int32_t* colind,
                                float* colval, float* cnorms);
 double matrix_setup_ms(const slimgpu_matrix_t* m);
+int32_t matrix_column_cost(const slimgpu_matrix_t* m, int64_t* cost);
 
 // EstimateModelCD + SaveModel on the device matrix.  Returns a host model
 // (slim_csr_t with both views) or nullptr with *status set.

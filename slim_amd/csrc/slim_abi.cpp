@@ -350,6 +350,10 @@ int32_t SLIMGPU_MatrixGetColumnView(const slimgpu_matrix_t* mat, int64_t* colptr
   return matrix_get_column_view(mat, colptr, colind, colval, cnorms);
 }
 
+int32_t SLIMGPU_MatrixColumnCost(const slimgpu_matrix_t* mat, int64_t* cost) {
+  return matrix_column_cost(mat, cost);
+}
+
 slim_t* SLIMGPU_Learn(slimgpu_matrix_t* mat, int32_t* ioptions, double* doptions, slim_t* imodel,
                       int32_t* r_status) {
   set_error("");

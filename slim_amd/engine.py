@@ -130,6 +130,13 @@ class DeviceMatrix(object):
             raise RuntimeError("SLIMGPU_MatrixGetColumnView failed: %s" % _lib.last_error())
         return colptr, colind[:self.nnz], colval[:self.nnz], cnorm
 
+    def column_cost(self):
+        cost = np.zeros(self.ncols, np.int64)
+        rc = self._lib.SLIMGPU_MatrixColumnCost(self.handle, cost.ctypes.data_as(C.c_void_p))
+        if rc != SLIM_OK:
+            raise RuntimeError("SLIMGPU_MatrixColumnCost failed")
+        return cost
+
     def learn(self, imodel=None, return_handle=False, **opts):
         """SLIMGPU_Learn.  Returns (W as scipy CSC, stats dict)."""
         iopt, dopt = make_options(**opts)
