@@ -1,0 +1,337 @@
+// cd_tile.hpp -- the CD solver for matrices whose residual does not fit in LDS.
+//
+// Why a second kernel.  With the residual r (one float per user) in HBM, the
+// one-wavefront-per-item kernel of cd_wave.hpp gathers 4 bytes from a random
+// 64-byte sector per nnz touched and re-streams the whole column view per item:
+// at 1M users x 100K items it moves ~16x more bytes than it uses.  Here a
+// workgroup of 16 wavefronts solves a TILE of P = 16 item columns together:
+//
+//   * residuals are interleaved, r[user][16]: the 16 problems' values of one
+//     user are one 64-byte sector, so every gather is a full sector and a
+//     wavefront load covers 4 users x 16 problems = 256 contiguous-by-sector bytes;
+//   * the 16 problems visit coordinates in the same order, so each column of R
+//     (ids + values) is read once per tile instead of once per item;
+//   * the nnz of the visited column are spread over the 16 wavefronts x 4 lane
+//     groups (64 nnz per workgroup step); the 16 dot products are reduced with
+//     two cross-lane adds + one LDS exchange per visit, every wavefront then
+//     evaluates the 16 soft-threshold updates redundantly (bitwise identical,
+//     so control flow stays workgroup-uniform) and applies the residual update
+//     to its own slice of the column.
+//
+// Per problem the arithmetic is exactly that of cd_wave.hpp (and of the
+// reference, src/libslim/cd.c:101-142): same update rule, same epsilon rule,
+// same stopping test, per-problem sweep cap min(50*nnz, maxniters); only the
+// visiting order differs -- a keyed permutation (cd_perm.hpp) of the UNION of
+// the tile's active sets, each problem skipping coordinates outside its own
+// active set.  The oracle has the same order (ORDER_TILE) for visit-for-visit
+// parity tests.
+//
+// x is kept dense and interleaved too, x[item][16], with -inf marking "not in
+// this problem's active set".
+#pragma once
+#include "cd_wave.hpp"
+
+namespace slimamd {
+
+constexpr int kTileP = 16;   // problems per tile
+constexpr int kTileNW = 16;  // wavefronts per workgroup
+constexpr float kInactive = -__builtin_huge_valf();
+__device__ __forceinline__ bool tile_active(float xv) { return xv > -3.0e38f; }
+
+template <bool HAS_VAL>
+__global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
+  constexpr int P = kTileP, NW = kTileNW;
+  __shared__ float s_part[2][NW][P];
+  __shared__ float s_red[2][NW][P];
+  __shared__ int s_item[P];
+  __shared__ int s_na[P];
+  __shared__ int s_grp, s_nunion;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int q = lane & (P - 1);  // problem handled by this lane
+  const int slot = lane >> 4;    // which of the 4 nnz of a wavefront step
+  const int g = wave * 4 + slot; // nnz slot inside the workgroup step, 0..63
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+
+  float* __restrict__ r = S.slab + (int64_t)blockIdx.x * S.slab_stride;   // [nrows][P]
+  float* __restrict__ x = S.xslab + (int64_t)blockIdx.x * S.x_stride;     // [ncols][P]
+  int* __restrict__ ul = S.ulist + (int64_t)blockIdx.x * S.u_stride;      // union list
+  const int64_t* __restrict__ colptr = A.colptr;
+  const int32_t* __restrict__ ci = A.colind;
+  const float* __restrict__ cv = A.colval;
+
+  const int nrows = A.nrows, ncols = A.ncols;
+  const float l1 = S.l1, l2 = S.l2;
+
+  for (;;) {
+    if (tid == 0) s_grp = atomicAdd(S.queue, 1);
+    __syncthreads();
+    const int grp = s_grp;
+    if (grp >= S.ngroups) break;
+    const int base = grp * P;
+    const int nprob = (S.nwork - base) < P ? (S.nwork - base) : P;
+    if (tid < P) {
+      s_item[tid] = tid < nprob ? S.order[base + tid] : -1;
+      s_na[tid] = 0;
+    }
+    // -- clear the interleaved work vectors
+    {
+      float4* r4 = reinterpret_cast<float4*>(r);
+      float4* x4 = reinterpret_cast<float4*>(x);
+      const int64_t nr4 = (int64_t)nrows * (P / 4), nx4 = (int64_t)ncols * (P / 4);
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int64_t k = tid; k < nr4; k += 1024) r4[k] = z;
+      for (int64_t k = tid; k < nx4; k += 1024) x4[k] = z;
+    }
+    __syncthreads();
+
+    // -- y scatter + Gram column: wavefront w serves problem w (estimate.c:406-421)
+    const int witem = s_item[wave];
+    int64_t Gw = 0;
+    if (witem >= 0) {
+      const int64_t cs = uni(colptr[witem]), ce = uni(colptr[witem + 1]);
+      for (int64_t jb = cs; jb < ce; jb += 64) {
+        const int64_t j = jb + lane;
+        const bool ok = j < ce;
+        const int u_l = ok ? ci[j] : 0;
+        const float v_l = ok ? (HAS_VAL ? cv[j] : 1.0f) : 0.0f;
+        const int64_t rs_l = ok ? A.rowptr[u_l] : 0;
+        const int64_t re_l = ok ? A.rowptr[u_l + 1] : 0;
+        if (ok) r[(int64_t)u_l * P + wave] = v_l;
+        const int cnt = (int)((ce - jb) < 64 ? (ce - jb) : 64);
+        for (int k = 0; k < cnt; ++k) {
+          const int64_t rs = lane_bcast(rs_l, k), re = lane_bcast(re_l, k);
+          const float v = lane_bcast(v_l, k);
+          Gw += re - rs;
+          for (int64_t e = rs + lane; e < re; e += 64) {
+            const float rv = HAS_VAL ? A.rowval[e] : 1.0f;
+            atomicAdd(&x[(int64_t)A.rowind[e] * P + wave], v * rv);
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // -- active sets (estimate.c:433-444): x = 0 for active, -inf for inactive
+    {
+      const int64_t n = (int64_t)ncols * P;
+      for (int64_t idx = tid; idx < n; idx += 1024) {
+        const int i = (int)(idx >> 4), qq = (int)(idx & (P - 1));
+        const int it = s_item[qq];
+        const bool act = it >= 0 && i != it && x[idx] > l1;
+        x[idx] = act ? 0.0f : kInactive;
+        if (act) atomicAdd(&s_na[qq], 1);
+      }
+    }
+    __syncthreads();
+
+    // -- warm start (estimate.c:453-464): previous coefficients of active coordinates
+    const bool warm = S.icolptr != nullptr;
+    if (warm && witem >= 0 && witem < S.incols) {
+      const int64_t ws = uni(S.icolptr[witem]), we = uni(S.icolptr[witem + 1]);
+      for (int64_t e = ws + lane; e < we; e += 64) {
+        const int k = S.icolind[e];
+        if (k < ncols) {
+          const int64_t a = (int64_t)k * P + wave;
+          if (tile_active(x[a])) x[a] = S.icolval[e];
+        }
+      }
+    }
+    if (warm) __syncthreads();
+
+    // -- union of the tile's active sets, ascending (wavefront 0)
+    if (wave == 0) {
+      int nu = 0;
+      for (int ib = 0; ib < ncols; ib += 64) {
+        const int i = ib + lane;
+        bool any = false;
+        if (i < ncols) {
+          const float4* row = reinterpret_cast<const float4*>(x + (int64_t)i * P);
+#pragma unroll
+          for (int c = 0; c < P / 4; ++c) {
+            const float4 f = row[c];
+            any |= tile_active(f.x) | tile_active(f.y) | tile_active(f.z) | tile_active(f.w);
+          }
+        }
+        const uint64_t m = __ballot(any);
+        if (any) ul[nu + __popcll(m & lane_lt)] = i;
+        nu += __popcll(m);
+      }
+      if (lane == 0) s_nunion = nu;
+    }
+    __syncthreads();
+    const int nunion = s_nunion;
+
+    // -- per-problem state, replicated in every lane that serves problem q
+    const int item_q = s_item[q];
+    int maxit_q = 0;
+    if (item_q >= 0) {
+      const int64_t cap = 50 * (colptr[item_q + 1] - colptr[item_q]);  // estimate.c:448-449
+      maxit_q = cap < (int64_t)S.maxniters ? (int)cap : S.maxniters;
+    }
+    bool done_q = item_q < 0;
+    int niters_q = 0, conv_q = 0;
+    int64_t D_q = 0, U_q = 0;
+    int buf = 0;
+
+    // one coordinate: dot for the 16 problems, update, residual axpy.
+    // mode 0: CD visit; mode 1: fold the warm-start coefficients into r (cd.c:108-110)
+    auto visit = [&](const int i, const bool live, float& dlt, const int mode) {
+      const int64_t s = uni(colptr[i]), e = uni(colptr[i + 1]);
+      const float xi = x[(int64_t)i * P + q];
+      const bool part = live && tile_active(xi);
+      if (!__any(part)) return;
+      float d = 0.0f, nx = xi;
+      if (mode == 0) {
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int64_t k = s + g; k < e; k += 64) {
+          const float v = HAS_VAL ? cv[k] : 1.0f;
+          acc += v * r[(int64_t)ci[k] * P + q];
+        }
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (slot == 0) s_part[buf][wave][q] = acc;
+        __syncthreads();
+        float dot = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dot += s_part[buf][w][q];
+        buf ^= 1;
+        const float cn = A.cnorm[i], sq = A.csq[i];
+        const float xeff = (xi > kEps || xi < -kEps) ? xi : 0.0f;
+        const float num = dot + xeff * sq;
+        nx = num > l1 ? (num - l1) / (cn * cn + l2) : 0.0f;
+        const float neff = (nx > kEps || nx < -kEps) ? nx : 0.0f;
+        d = neff - xeff;
+        if (!part) {
+          d = 0.0f;
+          nx = xi;
+        } else {
+          D_q += e - s;
+          dlt += (nx - xi) * (nx - xi);
+          if (d != 0.0f) U_q += e - s;
+        }
+      } else {
+        d = (part && (xi > kEps || xi < -kEps)) ? xi : 0.0f;
+      }
+      const bool upd = __any(d != 0.0f);
+      const bool xch = mode == 0 && __any(part && nx != xi);
+      if (upd) {
+        if (d != 0.0f) {
+#pragma unroll 4
+          for (int64_t k = s + g; k < e; k += 64) {
+            const float v = HAS_VAL ? cv[k] : 1.0f;
+            r[(int64_t)ci[k] * P + q] -= d * v;
+          }
+        }
+      }
+      if (xch && wave == 0 && slot == 0 && part && nx != xi) x[(int64_t)i * P + q] = nx;
+      if (upd || xch) __syncthreads();
+    };
+
+    if (warm) {
+      float unused = 0.0f;
+      for (int p = 0; p < nunion; ++p) visit(uni(ul[p]), !done_q, unused, 1);
+    }
+
+    // -- sweeps (cd.c:112-139)
+    for (int t = 0;; ++t) {
+      if (!done_q && t >= maxit_q) {  // loop exhausted without convergence: niters = t + 1
+        done_q = true;
+        niters_q = maxit_q + 1;
+      }
+      const bool live = !done_q;
+      if (!__any(live)) break;
+      float dlt = 0.0f;
+      const PermCtx pc = perm_make((uint32_t)nunion, perm_key(S.seed, (uint32_t)grp, (uint32_t)t));
+      for (int p = 0; p < nunion; ++p) {
+        const int i = uni(ul[perm_index(pc, (uint32_t)p)]);
+        visit(i, live, dlt, 0);
+      }
+      if (live && dlt < S.opt_tol) {  // cd.c:135-138
+        conv_q = 1;
+        done_q = true;
+        niters_q = t + 1;
+      }
+    }
+
+    // -- 1/2 ||r||^2 and the objective, per problem (estimate.c:477-489)
+    {
+      float e2 = 0.0f, reg = 0.0f;
+      for (int u = g; u < nrows; u += 64) {
+        const float rv = r[(int64_t)u * P + q];
+        e2 += rv * rv;
+      }
+      for (int i = g; i < ncols; i += 64) {
+        const float xv = x[(int64_t)i * P + q];
+        if (tile_active(xv)) reg += 0.5f * l2 * xv * xv + l1 * fabsf(xv);
+      }
+      e2 += __shfl_xor(e2, 16);
+      e2 += __shfl_xor(e2, 32);
+      reg += __shfl_xor(reg, 16);
+      reg += __shfl_xor(reg, 32);
+      if (slot == 0) {
+        s_red[0][wave][q] = e2;
+        s_red[1][wave][q] = reg;
+      }
+    }
+    __syncthreads();
+
+    // -- output: wavefront w compacts problem w (estimate.c:492-505)
+    if (witem >= 0) {
+      float err = 0.0f, reg = 0.0f;
+      for (int w = 0; w < NW; ++w) {
+        err += s_red[0][w][wave];
+        reg += s_red[1][w][wave];
+      }
+      err *= 0.5f;
+      int nz = 0;
+      for (int ib = 0; ib < ncols; ib += 64) {
+        const int i = ib + lane;
+        const float xv = i < ncols ? x[(int64_t)i * P + wave] : kInactive;
+        nz += __popcll(__ballot(tile_active(xv) && fabsf(xv) > kEps));
+      }
+      unsigned long long off = 0;
+      if (lane == 0) off = atomicAdd(S.out_cursor, (unsigned long long)nz);
+      off = (unsigned long long)uni((int64_t)off);
+      const bool fits = (int64_t)(off + (unsigned long long)nz) <= S.out_cap;
+      if (fits) {
+        int wpos = 0;
+        for (int ib = 0; ib < ncols; ib += 64) {
+          const int i = ib + lane;
+          const float xv = i < ncols ? x[(int64_t)i * P + wave] : kInactive;
+          const bool keep = tile_active(xv) && fabsf(xv) > kEps;
+          const uint64_t m = __ballot(keep);
+          if (keep) {
+            const int64_t dst = (int64_t)off + wpos + __popcll(m & lane_lt);
+            S.out_ind[dst] = i;
+            S.out_val[dst] = xv;
+          }
+          wpos += __popcll(m);
+        }
+      }
+      // lane `wave` (slot 0, q == wave) holds this problem's replicated counters
+      const int niters = lane_bcast(niters_q, wave);
+      const int conv = lane_bcast(conv_q, wave);
+      const int64_t Dw = lane_bcast(D_q, wave), Uw = lane_bcast(U_q, wave);
+      if (lane == 0) {
+        if (!fits) atomicExch(S.overflow, 1);
+        S.out_cnt[witem] = fits ? nz : -nz - 1;
+        S.out_off[witem] = (int64_t)off;
+        S.st_na[witem] = s_na[wave];
+        S.st_sweeps[witem] = niters;
+        S.st_conv[witem] = conv;
+        S.st_G[witem] = Gw;
+        S.st_D[witem] = Dw;
+        S.st_U[witem] = Uw;
+        S.st_err[witem] = err;
+        S.st_obj[witem] = err + reg;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace slimamd

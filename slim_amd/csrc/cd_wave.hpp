@@ -62,10 +62,16 @@ struct SolveArgs {
   const int32_t* icolind;
   const float* icolval;
   int32_t incols;
-  // per-wave HBM slab for the work vectors (HBM kernel only)
+  // per-wave HBM slab for the work vectors (HBM kernel only); for the tile kernel
+  // (cd_tile.hpp) slab = interleaved residuals, xslab = interleaved x, ulist = union list
   float* slab;
-  int64_t slab_stride;  // floats per wavefront
+  int64_t slab_stride;  // floats per wavefront / workgroup
   int32_t nrows_pad, ncols_pad;
+  float* xslab;
+  int64_t x_stride;
+  int32_t* ulist;
+  int64_t u_stride;
+  int32_t ngroups;      // tiles of 16 item columns in the work list
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;
   int64_t* out_off;

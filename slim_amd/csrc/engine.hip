@@ -19,6 +19,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include "cd_tile.hpp"
 #include "cd_wave.hpp"
 #include "engine.hpp"
 #include "host_csr.hpp"
@@ -50,7 +51,7 @@ struct slimgpu_matrix {
     size_t bytes = 0;
   };
   Buf ws_order, ws_cnt, ws_off, ws_stat_i, ws_stat_l, ws_stat_f, ws_misc, ws_arena_i, ws_arena_v,
-      ws_slab, ws_icolptr, ws_icolind, ws_icolval;
+      ws_slab, ws_xslab, ws_ulist, ws_icolptr, ws_icolind, ws_icolval;
 };
 
 namespace slimamd {
@@ -282,8 +283,8 @@ void destroy(slimgpu_matrix* m) {
   (void)hipFree(m->d_csq);
   for (slimgpu_matrix::Buf* b :
        {&m->ws_order, &m->ws_cnt, &m->ws_off, &m->ws_stat_i, &m->ws_stat_l, &m->ws_stat_f,
-        &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_icolptr, &m->ws_icolind,
-        &m->ws_icolval})
+        &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_xslab, &m->ws_ulist,
+        &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval})
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -502,19 +503,21 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     const int ncols_pad = round_up(ncols, 64);
     const size_t vec_floats = (size_t)nrows_pad + 2 * (size_t)ncols_pad;
     const size_t lds_need = vec_floats * sizeof(float);
-    bool use_lds;
-    if (opt.kernel == SLIMGPU_KERNEL_WAVE_LDS) {
-      if (lds_need > 160 * 1024) {
-        set_error("SLIMGPU_Learn: work vectors do not fit the 160 KiB LDS of a CU");
-        return fail(SLIM_ERROR_INPUT);
-      }
-      use_lds = true;
-    } else if (opt.kernel == SLIMGPU_KERNEL_WAVE_HBM) {
-      use_lds = false;
-    } else {
-      use_lds = lds_need <= 64 * 1024;
+    int kernel = opt.kernel;
+    if (kernel == SLIMGPU_KERNEL_AUTO)
+      kernel = lds_need <= 64 * 1024 ? SLIMGPU_KERNEL_WAVE_LDS : SLIMGPU_KERNEL_TILE;
+    if (kernel == SLIMGPU_KERNEL_WAVE_LDS && lds_need > 160 * 1024) {
+      set_error("SLIMGPU_Learn: work vectors do not fit the 160 KiB LDS of a CU");
+      return fail(SLIM_ERROR_INPUT);
     }
-    KernelFn fn = pick_kernel(use_lds, !m->binary);
+    if (kernel < SLIMGPU_KERNEL_WAVE_LDS || kernel > SLIMGPU_KERNEL_TILE) {
+      set_error("SLIMGPU_Learn: unknown kernel selection");
+      return fail(SLIM_ERROR_INPUT);
+    }
+    const bool use_lds = kernel == SLIMGPU_KERNEL_WAVE_LDS;
+    const bool use_tile = kernel == SLIMGPU_KERNEL_TILE;
+    KernelFn fn = use_tile ? (m->binary ? cd_tile_kernel<false> : cd_tile_kernel<true>)
+                           : pick_kernel(use_lds, !m->binary);
     int waves_per_cu;
     if (use_lds) {
       waves_per_cu = (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_need, 1));
@@ -525,7 +528,23 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     } else {
       waves_per_cu = 8;
     }
+    // wave kernels: one block = one wavefront; tile kernel: one block = 16 wavefronts
     int nwaves = std::max(1, std::min(nwork, m->num_cus * waves_per_cu));
+    const int tile_wgs_per_cu = 1;
+    size_t tile_r = 0, tile_x = 0, tile_u = 0;
+    if (use_tile) {
+      tile_r = (size_t)nrows_pad * kTileP;
+      tile_x = (size_t)ncols_pad * kTileP;
+      tile_u = (size_t)ncols_pad;
+      const int ngroups_all = (nwork + kTileP - 1) / kTileP;
+      nwaves = std::max(1, std::min(ngroups_all, m->num_cus * tile_wgs_per_cu));
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+      const size_t per_wg = (tile_r + tile_x) * sizeof(float) + tile_u * sizeof(int32_t);
+      const size_t have = free_b + m->ws_slab.bytes + m->ws_xslab.bytes + m->ws_ulist.bytes;
+      const size_t budget = have > (size_t(6) << 30) ? have - (size_t(6) << 30) : have / 2;
+      if ((size_t)nwaves * per_wg > budget) nwaves = (int)std::max<size_t>(1, budget / per_wg);
+    }
 
     // device buffers
     int32_t* d_order = ws_get<int32_t>(m->ws_order, (size_t)nwork);
@@ -537,7 +556,15 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     // misc: [0] queue (int32) [1] overflow (int32) [2..3] cursor (u64)
     int32_t* d_misc = ws_get<int32_t>(m->ws_misc, 4);
     float* d_slab = nullptr;
-    if (!use_lds) d_slab = ws_get<float>(m->ws_slab, vec_floats * (size_t)nwaves);
+    float* d_xslab = nullptr;
+    int32_t* d_ulist = nullptr;
+    if (use_tile) {
+      d_slab = ws_get<float>(m->ws_slab, tile_r * (size_t)nwaves);
+      d_xslab = ws_get<float>(m->ws_xslab, tile_x * (size_t)nwaves);
+      d_ulist = ws_get<int32_t>(m->ws_ulist, tile_u * (size_t)nwaves);
+    } else if (!use_lds) {
+      d_slab = ws_get<float>(m->ws_slab, vec_floats * (size_t)nwaves);
+    }
 
     int64_t arena_cap = std::max<int64_t>(1 << 20, 2 * m->nnz);
     const char* env_cap = std::getenv("SLIM_GPU_ARENA");
@@ -623,9 +650,14 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.icolval = d_icolval;
       S.incols = incols;
       S.slab = d_slab;
-      S.slab_stride = (int64_t)vec_floats;
+      S.slab_stride = use_tile ? (int64_t)tile_r : (int64_t)vec_floats;
       S.nrows_pad = nrows_pad;
       S.ncols_pad = ncols_pad;
+      S.xslab = d_xslab;
+      S.x_stride = (int64_t)tile_x;
+      S.ulist = d_ulist;
+      S.u_stride = (int64_t)tile_u;
+      S.ngroups = (npend + kTileP - 1) / kTileP;
       S.out_cnt = d_cnt;
       S.out_off = d_off;
       S.out_ind = d_ai;
@@ -642,9 +674,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.st_err = d_stf;
       S.st_obj = d_stf + ncols;
 
-      const int launch_waves = std::max(1, std::min(npend, nwaves));
+      const int launch_waves =
+          std::max(1, std::min(use_tile ? (npend + kTileP - 1) / kTileP : npend, nwaves));
       HIP_TRY(hipEventRecord(ev0, stream));
-      hipLaunchKernelGGL(fn, dim3(launch_waves), dim3(64), use_lds ? lds_need : 0, stream, A, S);
+      hipLaunchKernelGGL(fn, dim3(launch_waves), dim3(use_tile ? 64 * kTileNW : 64),
+                         use_lds ? lds_need : 0, stream, A, S);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(ev1, stream));
 
@@ -737,7 +771,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     slim_csr_t* model = model_from_columns(ncols, colptr, colind, colval);
 
     st.ncols_solved = nwork;
-    st.kernel = use_lds ? SLIMGPU_KERNEL_WAVE_LDS : SLIMGPU_KERNEL_WAVE_HBM;
+    st.kernel = kernel;
     st.nwaves = nwaves;
     st.lds_bytes = use_lds ? (int32_t)lds_need : 0;
     st.setup_ms = m->setup_ms;
