@@ -8,7 +8,7 @@
 //
 //   * residuals are interleaved, r[user][16]: the 16 problems' values of one
 //     user are one 64-byte sector, so every gather is a full sector and a
-//     wavefront load covers 4 users x 16 problems = 256 contiguous-by-sector bytes;
+//     wavefront load covers 4 users x 16 problems = four whole sectors;
 //   * the 16 problems visit coordinates in the same order, so each column of R
 //     (ids + values) is read once per tile instead of once per item;
 //   * the nnz of the visited column are spread over the 16 wavefronts x 4 lane
@@ -16,19 +16,27 @@
 //     two cross-lane adds + one LDS exchange per visit, every wavefront then
 //     evaluates the 16 soft-threshold updates redundantly (bitwise identical,
 //     so control flow stays workgroup-uniform) and applies the residual update
-//     to its own slice of the column.
+//     to its own slice of the column;
+//   * the first UB steps of a wavefront's slice (ids, values, gathered
+//     residuals) stay in registers between the dot and the update: the update
+//     is then store-only, and it stores all 16 problems of a user (changed or
+//     not), i.e. whole sectors -- no read-modify-write in L2/HBM.  Columns up to
+//     64*UB nnz are fully covered; the tail of longer columns is re-read;
+//   * the next visit's scalars (column id, offsets, x row, norms) are loaded one
+//     visit ahead.
 //
 // Per problem the arithmetic is exactly that of cd_wave.hpp (and of the
 // reference, src/libslim/cd.c:101-142): same update rule, same epsilon rule,
 // same stopping test, per-problem sweep cap min(50*nnz, maxniters); only the
 // visiting order differs -- a keyed permutation (cd_perm.hpp) of the UNION of
 // the tile's active sets, each problem skipping coordinates outside its own
-// active set.  The oracle has the same order (ORDER_TILE) for visit-for-visit
-// parity tests.
+// active set.
 //
 // x is kept dense and interleaved too, x[item][16], with -inf marking "not in
 // this problem's active set".
 #pragma once
+#include <type_traits>
+
 #include "cd_wave.hpp"
 
 namespace slimamd {
@@ -70,6 +78,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     __syncthreads();
     const int grp = s_grp;
     if (grp >= S.ngroups) break;
+    const uint64_t t_start = wall_clock64();
     const int base = grp * P;
     const int nprob = (S.nwork - base) < P ? (S.nwork - base) : P;
     if (tid < P) {
@@ -176,21 +185,69 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     int64_t D_q = 0, U_q = 0;
     int buf = 0;
 
-    // one coordinate: dot for the 16 problems, update, residual axpy.
+    // One coordinate: dot for the 16 problems, update, residual axpy.  The column is
+    // walked in chunks of 64*UB nnz (UB per lane group, all loads of a chunk in flight
+    // together); the LAST chunk stays in registers between dot and update.
     // mode 0: CD visit; mode 1: fold the warm-start coefficients into r (cd.c:108-110)
-    auto visit = [&](const int i, const bool live, float& dlt, const int mode) {
-      const int64_t s = uni(colptr[i]), e = uni(colptr[i + 1]);
-      const float xi = x[(int64_t)i * P + q];
+    auto visit = [&](auto ub_tag, const int i, const int64_t s, const int64_t e, const float xi,
+                     const float cn, const float sq, const bool live, float& dlt,
+                     const int mode) {
+      constexpr int UB = decltype(ub_tag)::value;
+      constexpr int64_t CH = 64 * UB;
       const bool part = live && tile_active(xi);
       if (!__any(part)) return;
+      const int64_t kclamp = e > s ? e - 1 : 0;
+      int u_c[UB];
+      float v_c[UB], r_c[UB];
+      // 32-bit byte offsets from wave-uniform bases: global_load with an SGPR base + one
+      // offset VGPR (the r slab of a workgroup is < 4 GiB, checked by the host)
+      const char* __restrict__ rb = reinterpret_cast<const char*>(r);
+      char* __restrict__ rbw = reinterpret_cast<char*>(r);
+      const uint32_t qoff = (uint32_t)q << 2;
+      auto load_chunk = [&](const int64_t c0) {
+        const char* __restrict__ cib = reinterpret_cast<const char*>(ci + c0);
+        const char* __restrict__ cvb = reinterpret_cast<const char*>(HAS_VAL ? cv + c0 : nullptr);
+        const uint32_t lim = (uint32_t)(e - c0 < CH ? e - c0 : CH);   // valid entries here
+        const uint32_t kc = (uint32_t)(kclamp >= c0 ? kclamp - c0 : 0);
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+          const uint32_t o = (uint32_t)g + 64u * (uint32_t)j;
+          const bool ok = o < lim;
+          const uint32_t bo = (ok ? o : kc) << 2;
+          u_c[j] = *reinterpret_cast<const int*>(cib + bo);
+          v_c[j] = ok ? (HAS_VAL ? *reinterpret_cast<const float*>(cvb + bo) : 1.0f) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < UB; ++j)
+          r_c[j] = *reinterpret_cast<const float*>(rb + (((uint32_t)u_c[j] << 6) | qoff));
+      };
+      auto store_chunk = [&](const int64_t c0, const float d) {
+        // whole sectors: every problem's value of the user is written back
+        const uint32_t lim = (uint32_t)(e - c0 < CH ? e - c0 : CH);
+#pragma unroll
+        for (int j = 0; j < UB; ++j) {
+          const uint32_t o = (uint32_t)g + 64u * (uint32_t)j;
+          if (o < lim)
+            *reinterpret_cast<float*>(rbw + (((uint32_t)u_c[j] << 6) | qoff)) =
+                r_c[j] - d * v_c[j];
+        }
+      };
+
+      float acc = 0.0f;
+      int64_t c0 = s;
+      for (; c0 + CH < e; c0 += CH) {
+        load_chunk(c0);
+        if (mode == 0) {
+#pragma unroll
+          for (int j = 0; j < UB; ++j) acc += v_c[j] * r_c[j];
+        }
+      }
+      load_chunk(c0);  // last chunk: kept for the update
+
       float d = 0.0f, nx = xi;
       if (mode == 0) {
-        float acc = 0.0f;
-#pragma unroll 4
-        for (int64_t k = s + g; k < e; k += 64) {
-          const float v = HAS_VAL ? cv[k] : 1.0f;
-          acc += v * r[(int64_t)ci[k] * P + q];
-        }
+#pragma unroll
+        for (int j = 0; j < UB; ++j) acc += v_c[j] * r_c[j];
         acc += __shfl_xor(acc, 16);
         acc += __shfl_xor(acc, 32);
         if (slot == 0) s_part[buf][wave][q] = acc;
@@ -199,7 +256,6 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
 #pragma unroll
         for (int w = 0; w < NW; ++w) dot += s_part[buf][w][q];
         buf ^= 1;
-        const float cn = A.cnorm[i], sq = A.csq[i];
         const float xeff = (xi > kEps || xi < -kEps) ? xi : 0.0f;
         const float num = dot + xeff * sq;
         nx = num > l1 ? (num - l1) / (cn * cn + l2) : 0.0f;
@@ -219,21 +275,38 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       const bool upd = __any(d != 0.0f);
       const bool xch = mode == 0 && __any(part && nx != xi);
       if (upd) {
-        if (d != 0.0f) {
-#pragma unroll 4
-          for (int64_t k = s + g; k < e; k += 64) {
-            const float v = HAS_VAL ? cv[k] : 1.0f;
-            r[(int64_t)ci[k] * P + q] -= d * v;
-          }
+        store_chunk(c0, d);
+        for (int64_t c = s; c < c0; c += CH) {  // earlier chunks: re-read (L2 / Infinity Cache)
+          load_chunk(c);
+          store_chunk(c, d);
         }
       }
       if (xch && wave == 0 && slot == 0 && part && nx != xi) x[(int64_t)i * P + q] = nx;
       if (upd || xch) __syncthreads();
     };
+    // pick the register tier from the (workgroup-uniform) column length
+    auto visit_any = [&](const int i, const int64_t s, const int64_t e, const float xi,
+                         const float cn, const float sq, const bool live, float& dlt,
+                         const int mode) {
+      const int64_t n = e - s;
+      if (n <= 64 * 2)
+        visit(std::integral_constant<int, 2>{}, i, s, e, xi, cn, sq, live, dlt, mode);
+      else if (n <= 64 * 4)
+        visit(std::integral_constant<int, 4>{}, i, s, e, xi, cn, sq, live, dlt, mode);
+      else if (n <= 64 * 8)
+        visit(std::integral_constant<int, 8>{}, i, s, e, xi, cn, sq, live, dlt, mode);
+      else
+        visit(std::integral_constant<int, 16>{}, i, s, e, xi, cn, sq, live, dlt, mode);
+    };
 
+    const uint64_t t_setup = wall_clock64();
     if (warm) {
       float unused = 0.0f;
-      for (int p = 0; p < nunion; ++p) visit(uni(ul[p]), !done_q, unused, 1);
+      for (int p = 0; p < nunion; ++p) {
+        const int i = uni(ul[p]);
+        visit_any(i, uni(colptr[i]), uni(colptr[i + 1]), x[(int64_t)i * P + q], 0.0f, 0.0f,
+                  !done_q, unused, 1);
+      }
     }
 
     // -- sweeps (cd.c:112-139)
@@ -246,9 +319,29 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       if (!__any(live)) break;
       float dlt = 0.0f;
       const PermCtx pc = perm_make((uint32_t)nunion, perm_key(S.seed, (uint32_t)grp, (uint32_t)t));
-      for (int p = 0; p < nunion; ++p) {
-        const int i = uni(ul[perm_index(pc, (uint32_t)p)]);
-        visit(i, live, dlt, 0);
+      if (nunion > 0) {
+        // two-deep software pipeline on the visit scalars: the column id two visits
+        // ahead and the offsets / x row / norms one visit ahead are in flight while the
+        // current column is processed (values stay in VGPRs until they are consumed)
+        int i_n1 = ul[perm_index(pc, 0u)];
+        int i_n2 = nunion > 1 ? ul[perm_index(pc, 1u)] : 0;
+        int64_t s_n = colptr[i_n1], e_n = colptr[i_n1 + 1];
+        float xi_n = x[(int64_t)i_n1 * P + q], cn_n = A.cnorm[i_n1], sq_n = A.csq[i_n1];
+        for (int p = 0; p < nunion; ++p) {
+          const int i = uni(i_n1);
+          const int64_t s = uni(s_n), e = uni(e_n);
+          const float xi = xi_n, cn = uni(cn_n), sq = uni(sq_n);
+          if (p + 1 < nunion) {
+            i_n1 = i_n2;
+            s_n = colptr[i_n1];
+            e_n = colptr[i_n1 + 1];
+            xi_n = x[(int64_t)i_n1 * P + q];
+            cn_n = A.cnorm[i_n1];
+            sq_n = A.csq[i_n1];
+            if (p + 2 < nunion) i_n2 = ul[perm_index(pc, (uint32_t)(p + 2))];
+          }
+          visit_any(i, s, e, xi, cn, sq, live, dlt, 0);
+        }
       }
       if (live && dlt < S.opt_tol) {  // cd.c:135-138
         conv_q = 1;
@@ -257,6 +350,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       }
     }
 
+    const uint64_t t_sweeps = wall_clock64();
     // -- 1/2 ||r||^2 and the objective, per problem (estimate.c:477-489)
     {
       float e2 = 0.0f, reg = 0.0f;
@@ -329,6 +423,15 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
         S.st_err[witem] = err;
         S.st_obj[witem] = err + reg;
       }
+    }
+    if (S.trace != nullptr && tid == 0) {
+      uint64_t* tr = S.trace + (int64_t)grp * 8;
+      tr[0] = t_start;
+      tr[1] = t_setup;
+      tr[2] = t_sweeps;
+      tr[3] = wall_clock64();
+      tr[4] = blockIdx.x;
+      tr[5] = (uint64_t)nunion;
     }
     __syncthreads();
   }

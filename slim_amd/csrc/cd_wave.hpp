@@ -72,6 +72,7 @@ struct SolveArgs {
   int32_t* ulist;
   int64_t u_stride;
   int32_t ngroups;      // tiles of 16 item columns in the work list
+  uint64_t* trace;      // optional per-tile timeline (SLIM_GPU_TRACE), 8 words per tile
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;
   int64_t* out_off;

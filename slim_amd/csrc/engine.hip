@@ -51,7 +51,7 @@ struct slimgpu_matrix {
     size_t bytes = 0;
   };
   Buf ws_order, ws_cnt, ws_off, ws_stat_i, ws_stat_l, ws_stat_f, ws_misc, ws_arena_i, ws_arena_v,
-      ws_slab, ws_xslab, ws_ulist, ws_icolptr, ws_icolind, ws_icolval;
+      ws_slab, ws_xslab, ws_ulist, ws_trace, ws_icolptr, ws_icolind, ws_icolval;
 };
 
 namespace slimamd {
@@ -284,7 +284,7 @@ void destroy(slimgpu_matrix* m) {
   for (slimgpu_matrix::Buf* b :
        {&m->ws_order, &m->ws_cnt, &m->ws_off, &m->ws_stat_i, &m->ws_stat_l, &m->ws_stat_f,
         &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_xslab, &m->ws_ulist,
-        &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval})
+        &m->ws_trace, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval})
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -658,6 +658,12 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.ulist = d_ulist;
       S.u_stride = (int64_t)tile_u;
       S.ngroups = (npend + kTileP - 1) / kTileP;
+      const bool trace = use_tile && std::getenv("SLIM_GPU_TRACE") != nullptr;
+      S.trace = nullptr;
+      if (trace) {
+        S.trace = ws_get<uint64_t>(m->ws_trace, 8 * (size_t)S.ngroups);
+        HIP_TRY(hipMemsetAsync(S.trace, 0, sizeof(uint64_t) * 8 * (size_t)S.ngroups, stream));
+      }
       S.out_cnt = d_cnt;
       S.out_off = d_off;
       S.out_ind = d_ai;
@@ -692,6 +698,31 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       float ms = 0;
       HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
       kernel_ms += ms;
+      if (S.trace) {  // per-tile timeline: where does the launch spend its time?
+        std::vector<uint64_t> tr(8 * (size_t)S.ngroups);
+        HIP_TRY(hipMemcpy(tr.data(), S.trace, sizeof(uint64_t) * tr.size(), hipMemcpyDeviceToHost));
+        uint64_t t0 = ~0ull, t1 = 0;
+        double busy = 0, setup = 0, sweeps = 0;
+        std::vector<double> dur;
+        for (int gI = 0; gI < S.ngroups; ++gI) {
+          const uint64_t* e = &tr[8 * (size_t)gI];
+          t0 = std::min(t0, e[0]);
+          t1 = std::max(t1, e[3]);
+          busy += double(e[3] - e[0]);
+          setup += double(e[1] - e[0]);
+          sweeps += double(e[2] - e[1]);
+          dur.push_back(double(e[3] - e[0]) * 1e-5);
+        }
+        std::sort(dur.begin(), dur.end());
+        const double span = double(t1 - t0);
+        std::fprintf(stderr,
+                     "[trace] tiles %d on %d workgroups: span %.2f ms (event %.2f ms), busy/"
+                     "(span*wgs) %.2f, setup %.1f%% sweeps %.1f%% of busy; tile ms min %.2f med "
+                     "%.2f p90 %.2f max %.2f\n",
+                     S.ngroups, launch_waves, span * 1e-5, ms,
+                     busy / (span * launch_waves), 100 * setup / busy, 100 * sweeps / busy,
+                     dur.front(), dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back());
+      }
 
       unsigned long long cursor;
       std::memcpy(&cursor, h_misc + 2, sizeof(cursor));

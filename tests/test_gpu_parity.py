@@ -17,7 +17,8 @@ import scipy.sparse as sp
 import slim_oracle as O
 from slim_amd import SLIM, SLIMatrix, _lib
 from slim_amd.constants import SLIM_NOPTIONS, SLIM_OK, Opt
-from slim_amd.engine import (KERNEL_WAVE_HBM, KERNEL_WAVE_LDS, DeviceMatrix, model_to_scipy)
+from slim_amd.engine import (KERNEL_TILE, KERNEL_WAVE_HBM, KERNEL_WAVE_LDS, DeviceMatrix,
+                             model_to_scipy)
 
 pytestmark = pytest.mark.gpu
 
@@ -270,13 +271,54 @@ def test_random_ratings(kernel):
     m.close()
 
 
-def test_large_rows_use_hbm_kernel_automatically():
-    R = _random_ratings(40000, 150, 0.01, 3)   # 4*(40000+300) > 64 KiB of work vectors
+# ---- the tile kernel (16 item columns per workgroup, interleaved residuals) --------------------
+# Its visiting order (a permutation of the union of 16 active sets) is not the oracle's, so
+# parity is checked at the order-independent level: the reference's own order-to-order
+# envelope at optTol 1e-7, the fixed point at a tight tolerance, optimality conditions.
+def test_tile_kernel_ml100k(ml100k, ml_dev, ml_gpu):
+    R, T = ml100k
+    W, st = ml_dev.learn(seed=1, kernel=KERNEL_TILE)
+    cs = ml_dev.column_stats()
+    assert st["kernel"] == KERNEL_TILE
+    assert maxdiff(W, ml_gpu[0]) <= 3e-3
+    assert np.array_equal(cs.nacols, ml_gpu[2].nacols) and np.array_equal(cs.G, ml_gpu[2].G)
+    assert abs(st["objval"] - ml_gpu[1]["objval"]) <= 1e-4 * st["objval"]
+    ev = O.evaluate(W, R, T)
+    assert "%.4f" % ev["hr"] == "0.3191" and "%.4f" % ev["arhr"] == "0.1504"
+    Wt, _ = ml_dev.learn(seed=1, kernel=KERNEL_TILE, optTol=1e-12, niters=100000)
+    Wr = O.learn_cd(R, order=O.ORDER_GLIBC, srand=1, aty=O.ATY_GRAM, optTol=1e-12,
+                    maxniters=100000, nthreads=8)
+    assert maxdiff(Wt, Wr) <= 2e-5
+    assert np.array_equal(O.predict(Wt, R, 10)[0], O.predict(Wr, R, 10)[0])
+    # column ranges that are not multiples of the tile size, and a single column
+    parts = [ml_dev.learn(seed=1, kernel=KERNEL_TILE, optTol=1e-12, niters=100000,
+                          col_begin=b, col_end=e)[0] for b, e in ((0, 37), (37, 38), (38, 200))]
+    got = parts[0] + parts[1] + parts[2]
+    assert maxdiff(got[:, :200], Wt[:, :200]) <= 2e-5 and got[:, 200:].nnz == 0
+
+
+def test_tile_kernel_ratings_and_warm_start():
+    R = _random_ratings(40000, 150, 0.01, 3)   # 4*(40000+300) > 64 KiB: no LDS kernel
     m = DeviceMatrix.from_scipy(R)
     W, st = m.learn(l1r=1.0, l2r=1.0, seed=2)
-    assert st["kernel"] == KERNEL_WAVE_HBM and st["lds_bytes"] == 0
-    Wo = O.learn_cd(R, order=O.ORDER_PERM, seed=2, aty=O.ATY_GRAM, nthreads=8)
-    assert maxdiff(W, Wo) <= 5e-5
+    assert st["kernel"] == KERNEL_TILE and st["lds_bytes"] == 0   # automatic choice
+    Wo, so, err, obj = O.learn_cd(R, order=O.ORDER_PERM, seed=2, aty=O.ATY_GRAM, nthreads=8,
+                                  return_stats=True)
+    assert maxdiff(W, Wo) <= 3e-3
+    assert abs(st["objval"] - obj) <= 1e-4 * obj and abs(st["error"] - err) <= 1e-4 * err
+    cs = m.column_stats()
+    assert np.array_equal(cs.nacols, so["nacols"]) and np.array_equal(cs.G, so["G"])
+    Wh, _ = m.learn(l1r=1.0, l2r=1.0, seed=2, kernel=KERNEL_WAVE_HBM)
+    assert maxdiff(Wh, Wo) <= 5e-5           # the wave kernel walks the oracle's order
+    Wt, _ = m.learn(optTol=1e-13, niters=100000)
+    Wr = O.learn_cd(R, order=O.ORDER_PERM, aty=O.ATY_GRAM, nthreads=8, optTol=1e-13,
+                    maxniters=100000)
+    assert maxdiff(Wt, Wr) <= 2e-5
+    # warm start through the tile kernel
+    first, _ = m.learn(l1r=3.0, l2r=1.0, optTol=1e-13, niters=100000)
+    warm, st_w = m.learn(l1r=1.0, l2r=1.0, optTol=1e-13, niters=100000, imodel=first)
+    cold_sweeps = m.learn(l1r=1.0, l2r=1.0, optTol=1e-13, niters=100000)[1]["sweeps"]
+    assert maxdiff(warm, Wr) <= 2e-5 and st_w["sweeps"] < cold_sweeps
     m.close()
 
 
