@@ -172,7 +172,7 @@ def main():
                                else "binary", batch),
                 "scale": args.scale, "columns_per_step_per_gpu": batch,
                 "parallelism": "columns block-partitioned over %d GPU(s), R replicated" % world,
-                "kernel": {0: "auto", 1: "wave-lds", 2: "wave-hbm", 3: "tile16"}.get(st["kernel"], st["kernel"]),
+                "kernel": {0: "auto", 1: "wave-lds", 2: "wave-hbm", 3: "tile32", 4: "tile16"}.get(st["kernel"], st["kernel"]),
                 "generate_s": round(t_gen, 2), "stage_s": round(t_stage, 2),
             },
             "roofline": {

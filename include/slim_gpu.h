@@ -107,8 +107,9 @@ typedef enum {
   SLIMGPU_KERNEL_AUTO = 0,
   SLIMGPU_KERNEL_WAVE_LDS = 1, /* one wavefront per item, work vectors in LDS  */
   SLIMGPU_KERNEL_WAVE_HBM = 2, /* one wavefront per item, work vectors in HBM  */
-  SLIMGPU_KERNEL_TILE = 3      /* one workgroup per 16 items, interleaved
-                                  residuals in HBM (large matrices)            */
+  SLIMGPU_KERNEL_TILE = 3,     /* one workgroup per 32 items, residuals
+                                  interleaved r[user][32] in HBM (large matrices) */
+  SLIMGPU_KERNEL_TILE16 = 4    /* same with 16 items per workgroup             */
 } slimgpu_kernel_et;
 
 /* A training matrix staged in HBM: CSR as given + the column view (CSC, rows

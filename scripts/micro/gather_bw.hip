@@ -1,0 +1,67 @@
+// Microbenchmark: random-sector gather bandwidth on MI355X as a function of the
+// contiguous granule per 16-lane group.  Not part of the product.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+__device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+
+// GRAN = bytes contiguous per lane group (64, 128, 256); lanes per group = GRAN/4
+template <int GRAN, int UNROLL>
+__global__ __launch_bounds__(1024) void gather(const float* __restrict__ buf, uint32_t ngran, int iters, float* out) {
+  const int lane = threadIdx.x & 63;
+  constexpr int LPG = GRAN / 4;           // lanes per granule
+  const int grp = lane / LPG, sub = lane % LPG;
+  const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  float acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    float v[UNROLL];
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) {
+      uint32_t g = mix(wid * 7919u + (uint32_t)(it * UNROLL + j) * 64u + (uint32_t)grp) % ngran;
+      v[j] = buf[(size_t)g * LPG + sub];
+    }
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) acc += v[j];
+  }
+  if (acc == 123.456f) out[0] = acc;
+}
+
+template <int GRAN, int UNROLL>
+void run(const float* buf, size_t bytes, int blocks, int threads, int iters, float* out) {
+  uint32_t ngran = (uint32_t)(bytes / GRAN);
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  hipLaunchKernelGGL((gather<GRAN, UNROLL>), dim3(blocks), dim3(threads), 0, 0, buf, ngran, 4, out);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  hipLaunchKernelGGL((gather<GRAN, UNROLL>), dim3(blocks), dim3(threads), 0, 0, buf, ngran, iters, out);
+  CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  double waves = (double)blocks * threads / 64;
+  double bytes_moved = waves * iters * UNROLL * 256.0;
+  printf("gran %3d B unroll %2d blocks %4d x %4d thr: %8.1f GB/s  (%.1f GB/s per block)\n", GRAN, UNROLL, blocks, threads,
+         bytes_moved / ms / 1e6, bytes_moved / ms / 1e6 / blocks);
+}
+
+int main(int argc, char** argv) {
+  size_t bytes = (size_t)16 << 30;   // 16 GiB region
+  float* buf; CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 0, bytes));
+  float* out; CK(hipMalloc(&out, 4));
+  int iters = 2000;
+  for (int blocks : {1, 256, 512}) {
+    for (int threads : {256, 1024}) {
+      run<64, 16>(buf, bytes, blocks, threads, iters, out);
+      run<128, 16>(buf, bytes, blocks, threads, iters, out);
+      run<256, 16>(buf, bytes, blocks, threads, iters, out);
+    }
+  }
+  run<64, 4>(buf, bytes, 256, 1024, iters, out);
+  run<64, 32>(buf, bytes, 256, 1024, iters / 2, out);
+  run<128, 32>(buf, bytes, 256, 1024, iters / 2, out);
+  // small region (64 MiB): TLB / cache effects
+  run<64, 16>(buf, (size_t)64 << 20, 1, 1024, iters, out);
+  run<64, 16>(buf, (size_t)64 << 20, 256, 1024, iters, out);
+  return 0;
+}

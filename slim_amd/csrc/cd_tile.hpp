@@ -2,26 +2,32 @@
 //
 // Why a second kernel.  With the residual r (one float per user) in HBM, the
 // one-wavefront-per-item kernel of cd_wave.hpp gathers 4 bytes from a random
-// 64-byte sector per nnz touched and re-streams the whole column view per item:
-// at 1M users x 100K items it moves ~16x more bytes than it uses.  Here a
-// workgroup of 16 wavefronts solves a TILE of P = 16 item columns together:
+// sector per nnz touched and re-streams the whole column view per item: at
+// 1M users x 100K items it moves ~16x more bytes than it uses.  Here a
+// workgroup of 16 wavefronts solves a TILE of P item columns together
+// (P = 32 by default, 16 optional):
 //
-//   * residuals are interleaved, r[user][16]: the 16 problems' values of one
-//     user are one 64-byte sector, so every gather is a full sector and a
-//     wavefront load covers 4 users x 16 problems = four whole sectors;
-//   * the 16 problems visit coordinates in the same order, so each column of R
-//     (ids + values) is read once per tile instead of once per item;
-//   * the nnz of the visited column are spread over the 16 wavefronts x 4 lane
-//     groups (64 nnz per workgroup step); the 16 dot products are reduced with
-//     two cross-lane adds + one LDS exchange per visit, every wavefront then
-//     evaluates the 16 soft-threshold updates redundantly (bitwise identical,
-//     so control flow stays workgroup-uniform) and applies the residual update
-//     to its own slice of the column;
-//   * the first UB steps of a wavefront's slice (ids, values, gathered
-//     residuals) stay in registers between the dot and the update: the update
-//     is then store-only, and it stores all 16 problems of a user (changed or
-//     not), i.e. whole sectors -- no read-modify-write in L2/HBM.  Columns up to
-//     64*UB nnz are fully covered; the tail of longer columns is re-read;
+//   * residuals are interleaved, r[user][P].  Measured on MI355X
+//     (scripts/micro/gather_bw.hip): random 64-byte granules saturate the chip
+//     at 3.2 TB/s, random 128-byte granules at 6.0 TB/s -- the fabric is bound
+//     by request count below a full 128-byte line.  With P = 32 the 32
+//     problems' values of one user ARE one 128-byte line, so every gather and
+//     every write-back is a whole line;
+//   * the P problems visit coordinates in the same order, so each column of R
+//     (ids + values) is read once per tile instead of once per item, with
+//     coalesced loads: wavefront w of the workgroup owns 64 consecutive nnz of
+//     each 1024-nnz chunk of the visited column, loads their ids/values with one
+//     256-byte request each, and hands them to its lane groups through the
+//     cross-lane network (no LDS staging, no extra barrier);
+//   * a wavefront step covers 64/P users x P problems; all steps of a chunk
+//     (P loads per lane) are in flight together.  The P dot products are reduced
+//     with log2(64/P) cross-lane adds + one LDS exchange per visit; every
+//     wavefront then evaluates the P soft-threshold updates redundantly (bitwise
+//     identical, so control flow stays workgroup-uniform) and applies the
+//     residual update to its own nnz, storing whole lines (all P problems of a
+//     user, changed or not -- no read-modify-write in L2/HBM);
+//   * the last chunk of a column stays in registers between dot and update
+//     (store-only update); earlier chunks of long columns are re-read;
 //   * the next visit's scalars (column id, offsets, x row, norms) are loaded one
 //     visit ahead.
 //
@@ -32,7 +38,7 @@
 // the tile's active sets, each problem skipping coordinates outside its own
 // active set.
 //
-// x is kept dense and interleaved too, x[item][16], with -inf marking "not in
+// x is kept dense and interleaved too, x[item][P], with -inf marking "not in
 // this problem's active set".
 #pragma once
 #include <type_traits>
@@ -41,14 +47,23 @@
 
 namespace slimamd {
 
-constexpr int kTileP = 16;   // problems per tile
 constexpr int kTileNW = 16;  // wavefronts per workgroup
 constexpr float kInactive = -__builtin_huge_valf();
 __device__ __forceinline__ bool tile_active(float xv) { return xv > -3.0e38f; }
 
-template <bool HAS_VAL>
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(int& v) { asm volatile("" : "+v"(v)); }
+
+// PROFILE adds s_memtime stamps around the phases of a visit (SLIM_GPU_TRACE=2); the
+// waits it needs perturb the schedule a little, so it is a separate instantiation.
+template <int P, bool HAS_VAL, bool PROFILE>
 __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
-  constexpr int P = kTileP, NW = kTileNW;
+  constexpr int NW = kTileNW;
+  constexpr int SL = 64 / P;       // users per wavefront step (lane groups)
+  constexpr int STEPS = 64 / SL;   // steps per 64-nnz block (== P)
+  constexpr int PPW = P / NW;      // problems served per wavefront in the per-problem phases
+  constexpr int LOGP = P == 32 ? 5 : 4;
+  static_assert(P == 16 || P == 32, "tile width");
   __shared__ float s_part[2][NW][P];
   __shared__ float s_red[2][NW][P];
   __shared__ int s_item[P];
@@ -59,8 +74,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
   const int lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int q = lane & (P - 1);  // problem handled by this lane
-  const int slot = lane >> 4;    // which of the 4 nnz of a wavefront step
-  const int g = wave * 4 + slot; // nnz slot inside the workgroup step, 0..63
+  const int slot = lane >> LOGP; // which user of a wavefront step
   const uint64_t lane_lt = (1ull << lane) - 1ull;
 
   float* __restrict__ r = S.slab + (int64_t)blockIdx.x * S.slab_stride;   // [nrows][P]
@@ -96,27 +110,32 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     }
     __syncthreads();
 
-    // -- y scatter + Gram column: wavefront w serves problem w (estimate.c:406-421)
-    const int witem = s_item[wave];
-    int64_t Gw = 0;
-    if (witem >= 0) {
-      const int64_t cs = uni(colptr[witem]), ce = uni(colptr[witem + 1]);
-      for (int64_t jb = cs; jb < ce; jb += 64) {
-        const int64_t j = jb + lane;
-        const bool ok = j < ce;
-        const int u_l = ok ? ci[j] : 0;
-        const float v_l = ok ? (HAS_VAL ? cv[j] : 1.0f) : 0.0f;
-        const int64_t rs_l = ok ? A.rowptr[u_l] : 0;
-        const int64_t re_l = ok ? A.rowptr[u_l + 1] : 0;
-        if (ok) r[(int64_t)u_l * P + wave] = v_l;
-        const int cnt = (int)((ce - jb) < 64 ? (ce - jb) : 64);
-        for (int k = 0; k < cnt; ++k) {
-          const int64_t rs = lane_bcast(rs_l, k), re = lane_bcast(re_l, k);
-          const float v = lane_bcast(v_l, k);
-          Gw += re - rs;
-          for (int64_t e = rs + lane; e < re; e += 64) {
-            const float rv = HAS_VAL ? A.rowval[e] : 1.0f;
-            atomicAdd(&x[(int64_t)A.rowind[e] * P + wave], v * rv);
+    // -- y scatter + Gram column: wavefront w serves problems w, w+16 (estimate.c:406-421)
+    int64_t Gw[PPW];
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) {
+      const int pq = wave + pp * NW;
+      const int witem = s_item[pq];
+      Gw[pp] = 0;
+      if (witem >= 0) {
+        const int64_t cs = uni(colptr[witem]), ce = uni(colptr[witem + 1]);
+        for (int64_t jb = cs; jb < ce; jb += 64) {
+          const int64_t j = jb + lane;
+          const bool ok = j < ce;
+          const int u_l = ok ? ci[j] : 0;
+          const float v_l = ok ? (HAS_VAL ? cv[j] : 1.0f) : 0.0f;
+          const int64_t rs_l = ok ? A.rowptr[u_l] : 0;
+          const int64_t re_l = ok ? A.rowptr[u_l + 1] : 0;
+          if (ok) r[(int64_t)u_l * P + pq] = v_l;
+          const int cnt = (int)((ce - jb) < 64 ? (ce - jb) : 64);
+          for (int k = 0; k < cnt; ++k) {
+            const int64_t rs = lane_bcast(rs_l, k), re = lane_bcast(re_l, k);
+            const float v = lane_bcast(v_l, k);
+            Gw[pp] += re - rs;
+            for (int64_t e = rs + lane; e < re; e += 64) {
+              const float rv = HAS_VAL ? A.rowval[e] : 1.0f;
+              atomicAdd(&x[(int64_t)A.rowind[e] * P + pq], v * rv);
+            }
           }
         }
       }
@@ -127,7 +146,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     {
       const int64_t n = (int64_t)ncols * P;
       for (int64_t idx = tid; idx < n; idx += 1024) {
-        const int i = (int)(idx >> 4), qq = (int)(idx & (P - 1));
+        const int i = (int)(idx >> LOGP), qq = (int)(idx & (P - 1));
         const int it = s_item[qq];
         const bool act = it >= 0 && i != it && x[idx] > l1;
         x[idx] = act ? 0.0f : kInactive;
@@ -138,17 +157,24 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
 
     // -- warm start (estimate.c:453-464): previous coefficients of active coordinates
     const bool warm = S.icolptr != nullptr;
-    if (warm && witem >= 0 && witem < S.incols) {
-      const int64_t ws = uni(S.icolptr[witem]), we = uni(S.icolptr[witem + 1]);
-      for (int64_t e = ws + lane; e < we; e += 64) {
-        const int k = S.icolind[e];
-        if (k < ncols) {
-          const int64_t a = (int64_t)k * P + wave;
-          if (tile_active(x[a])) x[a] = S.icolval[e];
+    if (warm) {
+#pragma unroll
+      for (int pp = 0; pp < PPW; ++pp) {
+        const int pq = wave + pp * NW;
+        const int witem = s_item[pq];
+        if (witem >= 0 && witem < S.incols) {
+          const int64_t ws = uni(S.icolptr[witem]), we = uni(S.icolptr[witem + 1]);
+          for (int64_t e = ws + lane; e < we; e += 64) {
+            const int k = S.icolind[e];
+            if (k < ncols) {
+              const int64_t a = (int64_t)k * P + pq;
+              if (tile_active(x[a])) x[a] = S.icolval[e];
+            }
+          }
         }
       }
+      __syncthreads();
     }
-    if (warm) __syncthreads();
 
     // -- union of the tile's active sets, ascending (wavefront 0)
     if (wave == 0) {
@@ -184,71 +210,94 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     int niters_q = 0, conv_q = 0;
     int64_t D_q = 0, U_q = 0;
     int buf = 0;
+    // PROFILE: [0] loads of the dot, [1] reduce + barrier, [2] update math, [3] stores issued,
+    // [4] closing barrier, [5] visits, [6] visits with an update
+    uint64_t prof[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto tick = [&]() -> uint64_t {
+      if (!PROFILE) return 0;
+      __builtin_amdgcn_s_waitcnt(0);
+      return clock64();
+    };
 
-    // One coordinate: dot for the 16 problems, update, residual axpy.  The column is
-    // walked in chunks of 64*UB nnz (UB per lane group, all loads of a chunk in flight
-    // together); the LAST chunk stays in registers between dot and update.
+    const char* __restrict__ rb = reinterpret_cast<const char*>(r);
+    char* __restrict__ rbw = reinterpret_cast<char*>(r);
+    const uint32_t qoff = (uint32_t)q << 2;
+
+    // One coordinate: dot for the P problems, update, residual axpy.
     // mode 0: CD visit; mode 1: fold the warm-start coefficients into r (cd.c:108-110)
-    auto visit = [&](auto ub_tag, const int i, const int64_t s, const int64_t e, const float xi,
-                     const float cn, const float sq, const bool live, float& dlt,
-                     const int mode) {
-      constexpr int UB = decltype(ub_tag)::value;
-      constexpr int64_t CH = 64 * UB;
+    auto visit = [&](const int i, const int64_t s, const int64_t e, const float xi, const float cn,
+                     const float sq, const bool live, float& dlt, const int mode) {
       const bool part = live && tile_active(xi);
       if (!__any(part)) return;
-      const int64_t kclamp = e > s ? e - 1 : 0;
-      int u_c[UB];
-      float v_c[UB], r_c[UB];
-      // 32-bit byte offsets from wave-uniform bases: global_load with an SGPR base + one
-      // offset VGPR (the r slab of a workgroup is < 4 GiB, checked by the host)
-      const char* __restrict__ rb = reinterpret_cast<const char*>(r);
-      char* __restrict__ rbw = reinterpret_cast<char*>(r);
-      const uint32_t qoff = (uint32_t)q << 2;
-      auto load_chunk = [&](const int64_t c0) {
-        const char* __restrict__ cib = reinterpret_cast<const char*>(ci + c0);
-        const char* __restrict__ cvb = reinterpret_cast<const char*>(HAS_VAL ? cv + c0 : nullptr);
-        const uint32_t lim = (uint32_t)(e - c0 < CH ? e - c0 : CH);   // valid entries here
-        const uint32_t kc = (uint32_t)(kclamp >= c0 ? kclamp - c0 : 0);
-#pragma unroll
-        for (int j = 0; j < UB; ++j) {
-          const uint32_t o = (uint32_t)g + 64u * (uint32_t)j;
-          const bool ok = o < lim;
-          const uint32_t bo = (ok ? o : kc) << 2;
-          u_c[j] = *reinterpret_cast<const int*>(cib + bo);
-          v_c[j] = ok ? (HAS_VAL ? *reinterpret_cast<const float*>(cvb + bo) : 1.0f) : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < UB; ++j)
-          r_c[j] = *reinterpret_cast<const float*>(rb + (((uint32_t)u_c[j] << 6) | qoff));
+      constexpr int64_t CH = 64 * NW;  // nnz per workgroup chunk
+      int idreg = 0;
+      float vreg = 0.0f;
+      float r_c[STEPS];
+      int nhere = 0;  // valid nnz of this wavefront's 64-block in the current chunk
+      // this wavefront's 64 consecutive nnz of chunk c0: one coalesced request per array
+      auto load_ids = [&](const int64_t c0) {
+        const int64_t b0 = c0 + 64 * wave;
+        const int64_t left = e - b0;
+        nhere = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+        const bool ok = lane < nhere;
+        idreg = ok ? ci[b0 + lane] : 0;
+        vreg = ok ? (HAS_VAL ? cv[b0 + lane] : 1.0f) : 0.0f;
       };
-      auto store_chunk = [&](const int64_t c0, const float d) {
-        // whole sectors: every problem's value of the user is written back
-        const uint32_t lim = (uint32_t)(e - c0 < CH ? e - c0 : CH);
+      // gather the residual lines of the block: STEPS loads per lane in flight
+      auto gather = [&]() {
+        if (nhere > 0) {
 #pragma unroll
-        for (int j = 0; j < UB; ++j) {
-          const uint32_t o = (uint32_t)g + 64u * (uint32_t)j;
-          if (o < lim)
-            *reinterpret_cast<float*>(rbw + (((uint32_t)u_c[j] << 6) | qoff)) =
-                r_c[j] - d * v_c[j];
+          for (int j = 0; j < STEPS; ++j) {
+            const int src = j * SL + slot;
+            const int u = __shfl(idreg, src);
+            r_c[j] = 0.0f;
+            if (src < nhere)
+              r_c[j] = *reinterpret_cast<const float*>(rb + (((uint32_t)u * (uint32_t)(4 * P)) | qoff));
+          }
+#pragma unroll
+          for (int j = 0; j < STEPS; ++j) pin(r_c[j]);
+        }
+      };
+      auto dot_block = [&]() -> float {
+        float a = 0.0f;
+        if (nhere > 0) {
+#pragma unroll
+          for (int j = 0; j < STEPS; ++j) a += __shfl(vreg, j * SL + slot) * r_c[j];
+        }
+        return a;
+      };
+      // whole lines: every problem's value of the user is written back
+      auto scatter = [&](const float d) {
+        if (nhere > 0) {
+#pragma unroll
+          for (int j = 0; j < STEPS; ++j) {
+            const int src = j * SL + slot;
+            const int u = __shfl(idreg, src);
+            const float v = __shfl(vreg, src);
+            if (src < nhere)
+              *reinterpret_cast<float*>(rbw + (((uint32_t)u * (uint32_t)(4 * P)) | qoff)) =
+                  r_c[j] - d * v;
+          }
         }
       };
 
+      const uint64_t p0 = tick();
       float acc = 0.0f;
       int64_t c0 = s;
       for (; c0 + CH < e; c0 += CH) {
-        load_chunk(c0);
-        if (mode == 0) {
-#pragma unroll
-          for (int j = 0; j < UB; ++j) acc += v_c[j] * r_c[j];
-        }
+        load_ids(c0);
+        gather();
+        if (mode == 0) acc += dot_block();
       }
-      load_chunk(c0);  // last chunk: kept for the update
+      load_ids(c0);  // last chunk: kept in registers for the update
+      gather();
+      const uint64_t p1 = tick();
 
       float d = 0.0f, nx = xi;
+      uint64_t p2 = p1;
       if (mode == 0) {
-#pragma unroll
-        for (int j = 0; j < UB; ++j) acc += v_c[j] * r_c[j];
-        acc += __shfl_xor(acc, 16);
+        acc += dot_block();
+        if (SL == 4) acc += __shfl_xor(acc, 16);
         acc += __shfl_xor(acc, 32);
         if (slot == 0) s_part[buf][wave][q] = acc;
         __syncthreads();
@@ -256,6 +305,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
 #pragma unroll
         for (int w = 0; w < NW; ++w) dot += s_part[buf][w][q];
         buf ^= 1;
+        p2 = tick();
         const float xeff = (xi > kEps || xi < -kEps) ? xi : 0.0f;
         const float num = dot + xeff * sq;
         nx = num > l1 ? (num - l1) / (cn * cn + l2) : 0.0f;
@@ -274,29 +324,28 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       }
       const bool upd = __any(d != 0.0f);
       const bool xch = mode == 0 && __any(part && nx != xi);
+      const uint64_t p3 = tick();
       if (upd) {
-        store_chunk(c0, d);
+        scatter(d);
         for (int64_t c = s; c < c0; c += CH) {  // earlier chunks: re-read (L2 / Infinity Cache)
-          load_chunk(c);
-          store_chunk(c, d);
+          load_ids(c);
+          gather();
+          scatter(d);
         }
       }
       if (xch && wave == 0 && slot == 0 && part && nx != xi) x[(int64_t)i * P + q] = nx;
+      const uint64_t p4 = PROFILE ? clock64() : 0;
       if (upd || xch) __syncthreads();
-    };
-    // pick the register tier from the (workgroup-uniform) column length
-    auto visit_any = [&](const int i, const int64_t s, const int64_t e, const float xi,
-                         const float cn, const float sq, const bool live, float& dlt,
-                         const int mode) {
-      const int64_t n = e - s;
-      if (n <= 64 * 2)
-        visit(std::integral_constant<int, 2>{}, i, s, e, xi, cn, sq, live, dlt, mode);
-      else if (n <= 64 * 4)
-        visit(std::integral_constant<int, 4>{}, i, s, e, xi, cn, sq, live, dlt, mode);
-      else if (n <= 64 * 8)
-        visit(std::integral_constant<int, 8>{}, i, s, e, xi, cn, sq, live, dlt, mode);
-      else
-        visit(std::integral_constant<int, 16>{}, i, s, e, xi, cn, sq, live, dlt, mode);
+      if (PROFILE) {
+        const uint64_t p5 = clock64();
+        prof[0] += p1 - p0;
+        prof[1] += p2 - p1;
+        prof[2] += p3 - p2;
+        prof[3] += p4 - p3;
+        prof[4] += p5 - p4;
+        prof[5] += 1;
+        prof[6] += upd ? 1 : 0;
+      }
     };
 
     const uint64_t t_setup = wall_clock64();
@@ -304,8 +353,8 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       float unused = 0.0f;
       for (int p = 0; p < nunion; ++p) {
         const int i = uni(ul[p]);
-        visit_any(i, uni(colptr[i]), uni(colptr[i + 1]), x[(int64_t)i * P + q], 0.0f, 0.0f,
-                  !done_q, unused, 1);
+        visit(i, uni(colptr[i]), uni(colptr[i + 1]), x[(int64_t)i * P + q], 0.0f, 0.0f, !done_q,
+              unused, 1);
       }
     }
 
@@ -340,7 +389,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
             sq_n = A.csq[i_n1];
             if (p + 2 < nunion) i_n2 = ul[perm_index(pc, (uint32_t)(p + 2))];
           }
-          visit_any(i, s, e, xi, cn, sq, live, dlt, 0);
+          visit(i, s, e, xi, cn, sq, live, dlt, 0);
         }
       }
       if (live && dlt < S.opt_tol) {  // cd.c:135-138
@@ -354,17 +403,20 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     // -- 1/2 ||r||^2 and the objective, per problem (estimate.c:477-489)
     {
       float e2 = 0.0f, reg = 0.0f;
-      for (int u = g; u < nrows; u += 64) {
+      const int g = wave * SL + slot;
+      for (int u = g; u < nrows; u += NW * SL) {
         const float rv = r[(int64_t)u * P + q];
         e2 += rv * rv;
       }
-      for (int i = g; i < ncols; i += 64) {
+      for (int i = g; i < ncols; i += NW * SL) {
         const float xv = x[(int64_t)i * P + q];
         if (tile_active(xv)) reg += 0.5f * l2 * xv * xv + l1 * fabsf(xv);
       }
-      e2 += __shfl_xor(e2, 16);
+      if (SL == 4) {
+        e2 += __shfl_xor(e2, 16);
+        reg += __shfl_xor(reg, 16);
+      }
       e2 += __shfl_xor(e2, 32);
-      reg += __shfl_xor(reg, 16);
       reg += __shfl_xor(reg, 32);
       if (slot == 0) {
         s_red[0][wave][q] = e2;
@@ -373,18 +425,22 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     }
     __syncthreads();
 
-    // -- output: wavefront w compacts problem w (estimate.c:492-505)
-    if (witem >= 0) {
+    // -- output: wavefront w compacts problems w, w+16 (estimate.c:492-505)
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) {
+      const int pq = wave + pp * NW;
+      const int witem = s_item[pq];
+      if (witem < 0) continue;
       float err = 0.0f, reg = 0.0f;
       for (int w = 0; w < NW; ++w) {
-        err += s_red[0][w][wave];
-        reg += s_red[1][w][wave];
+        err += s_red[0][w][pq];
+        reg += s_red[1][w][pq];
       }
       err *= 0.5f;
       int nz = 0;
       for (int ib = 0; ib < ncols; ib += 64) {
         const int i = ib + lane;
-        const float xv = i < ncols ? x[(int64_t)i * P + wave] : kInactive;
+        const float xv = i < ncols ? x[(int64_t)i * P + pq] : kInactive;
         nz += __popcll(__ballot(tile_active(xv) && fabsf(xv) > kEps));
       }
       unsigned long long off = 0;
@@ -395,7 +451,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
         int wpos = 0;
         for (int ib = 0; ib < ncols; ib += 64) {
           const int i = ib + lane;
-          const float xv = i < ncols ? x[(int64_t)i * P + wave] : kInactive;
+          const float xv = i < ncols ? x[(int64_t)i * P + pq] : kInactive;
           const bool keep = tile_active(xv) && fabsf(xv) > kEps;
           const uint64_t m = __ballot(keep);
           if (keep) {
@@ -406,18 +462,18 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
           wpos += __popcll(m);
         }
       }
-      // lane `wave` (slot 0, q == wave) holds this problem's replicated counters
-      const int niters = lane_bcast(niters_q, wave);
-      const int conv = lane_bcast(conv_q, wave);
-      const int64_t Dw = lane_bcast(D_q, wave), Uw = lane_bcast(U_q, wave);
+      // lane pq (slot 0, q == pq) holds this problem's replicated counters
+      const int niters = lane_bcast(niters_q, pq);
+      const int conv = lane_bcast(conv_q, pq);
+      const int64_t Dw = lane_bcast(D_q, pq), Uw = lane_bcast(U_q, pq);
       if (lane == 0) {
         if (!fits) atomicExch(S.overflow, 1);
         S.out_cnt[witem] = fits ? nz : -nz - 1;
         S.out_off[witem] = (int64_t)off;
-        S.st_na[witem] = s_na[wave];
+        S.st_na[witem] = s_na[pq];
         S.st_sweeps[witem] = niters;
         S.st_conv[witem] = conv;
-        S.st_G[witem] = Gw;
+        S.st_G[witem] = Gw[pp];
         S.st_D[witem] = Dw;
         S.st_U[witem] = Uw;
         S.st_err[witem] = err;
@@ -432,6 +488,10 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       tr[3] = wall_clock64();
       tr[4] = blockIdx.x;
       tr[5] = (uint64_t)nunion;
+      if (PROFILE) {
+        uint64_t* pr = S.trace + (int64_t)S.ngroups * 8 + (int64_t)grp * 8;
+        for (int k = 0; k < 7; ++k) pr[k] = prof[k];
+      }
     }
     __syncthreads();
   }

@@ -510,14 +510,33 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       set_error("SLIMGPU_Learn: work vectors do not fit the 160 KiB LDS of a CU");
       return fail(SLIM_ERROR_INPUT);
     }
-    if (kernel < SLIMGPU_KERNEL_WAVE_LDS || kernel > SLIMGPU_KERNEL_TILE) {
+    if (kernel < SLIMGPU_KERNEL_WAVE_LDS || kernel > SLIMGPU_KERNEL_TILE16) {
       set_error("SLIMGPU_Learn: unknown kernel selection");
       return fail(SLIM_ERROR_INPUT);
     }
     const bool use_lds = kernel == SLIMGPU_KERNEL_WAVE_LDS;
-    const bool use_tile = kernel == SLIMGPU_KERNEL_TILE;
-    KernelFn fn = use_tile ? (m->binary ? cd_tile_kernel<false> : cd_tile_kernel<true>)
-                           : pick_kernel(use_lds, !m->binary);
+    // tile width: 32 item columns per workgroup (128-byte residual lines) unless the row
+    // offsets would overflow the kernel's 32-bit byte offsets
+    int tileP = kernel == SLIMGPU_KERNEL_TILE16 ? 16 : 32;
+    if (kernel == SLIMGPU_KERNEL_TILE && (int64_t)nrows_pad * 128 >= (int64_t(1) << 32)) tileP = 16;
+    bool use_tile = kernel == SLIMGPU_KERNEL_TILE || kernel == SLIMGPU_KERNEL_TILE16;
+    if (use_tile && (int64_t)nrows_pad * 4 * tileP >= (int64_t(1) << 32)) {
+      use_tile = false;  // > 67M users: fall back to one wavefront per item
+      kernel = SLIMGPU_KERNEL_WAVE_HBM;
+    }
+    if (use_tile) kernel = tileP == 32 ? SLIMGPU_KERNEL_TILE : SLIMGPU_KERNEL_TILE16;
+    const char* trace_env = std::getenv("SLIM_GPU_TRACE");
+    const int trace_level = trace_env ? std::atoi(trace_env) : 0;
+    KernelFn fn = pick_kernel(use_lds, !m->binary);
+    if (use_tile) {
+      const bool prof = trace_level >= 2;
+      if (tileP == 32)
+        fn = m->binary ? (prof ? cd_tile_kernel<32, false, true> : cd_tile_kernel<32, false, false>)
+                       : (prof ? cd_tile_kernel<32, true, true> : cd_tile_kernel<32, true, false>);
+      else
+        fn = m->binary ? (prof ? cd_tile_kernel<16, false, true> : cd_tile_kernel<16, false, false>)
+                       : (prof ? cd_tile_kernel<16, true, true> : cd_tile_kernel<16, true, false>);
+    }
     int waves_per_cu;
     if (use_lds) {
       waves_per_cu = (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_need, 1));
@@ -533,10 +552,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     const int tile_wgs_per_cu = 1;
     size_t tile_r = 0, tile_x = 0, tile_u = 0;
     if (use_tile) {
-      tile_r = (size_t)nrows_pad * kTileP;
-      tile_x = (size_t)ncols_pad * kTileP;
+      tile_r = (size_t)nrows_pad * tileP;
+      tile_x = (size_t)ncols_pad * tileP;
       tile_u = (size_t)ncols_pad;
-      const int ngroups_all = (nwork + kTileP - 1) / kTileP;
+      const int ngroups_all = (nwork + tileP - 1) / tileP;
       nwaves = std::max(1, std::min(ngroups_all, m->num_cus * tile_wgs_per_cu));
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -657,12 +676,12 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.x_stride = (int64_t)tile_x;
       S.ulist = d_ulist;
       S.u_stride = (int64_t)tile_u;
-      S.ngroups = (npend + kTileP - 1) / kTileP;
-      const bool trace = use_tile && std::getenv("SLIM_GPU_TRACE") != nullptr;
+      S.ngroups = (npend + tileP - 1) / tileP;
+      const bool trace = use_tile && trace_level >= 1;
       S.trace = nullptr;
       if (trace) {
-        S.trace = ws_get<uint64_t>(m->ws_trace, 8 * (size_t)S.ngroups);
-        HIP_TRY(hipMemsetAsync(S.trace, 0, sizeof(uint64_t) * 8 * (size_t)S.ngroups, stream));
+        S.trace = ws_get<uint64_t>(m->ws_trace, 16 * (size_t)S.ngroups);
+        HIP_TRY(hipMemsetAsync(S.trace, 0, sizeof(uint64_t) * 16 * (size_t)S.ngroups, stream));
       }
       S.out_cnt = d_cnt;
       S.out_off = d_off;
@@ -681,7 +700,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.st_obj = d_stf + ncols;
 
       const int launch_waves =
-          std::max(1, std::min(use_tile ? (npend + kTileP - 1) / kTileP : npend, nwaves));
+          std::max(1, std::min(use_tile ? (npend + tileP - 1) / tileP : npend, nwaves));
       HIP_TRY(hipEventRecord(ev0, stream));
       hipLaunchKernelGGL(fn, dim3(launch_waves), dim3(use_tile ? 64 * kTileNW : 64),
                          use_lds ? lds_need : 0, stream, A, S);
@@ -699,7 +718,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
       kernel_ms += ms;
       if (S.trace) {  // per-tile timeline: where does the launch spend its time?
-        std::vector<uint64_t> tr(8 * (size_t)S.ngroups);
+        std::vector<uint64_t> tr(16 * (size_t)S.ngroups);
         HIP_TRY(hipMemcpy(tr.data(), S.trace, sizeof(uint64_t) * tr.size(), hipMemcpyDeviceToHost));
         uint64_t t0 = ~0ull, t1 = 0;
         double busy = 0, setup = 0, sweeps = 0;
@@ -722,6 +741,18 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
                      S.ngroups, launch_waves, span * 1e-5, ms,
                      busy / (span * launch_waves), 100 * setup / busy, 100 * sweeps / busy,
                      dur.front(), dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back());
+        if (trace_level >= 2) {
+          double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+          for (int gI = 0; gI < S.ngroups; ++gI)
+            for (int k = 0; k < 7; ++k) ph[k] += double(tr[8 * (size_t)S.ngroups + 8 * (size_t)gI + k]);
+          const double tot = ph[0] + ph[1] + ph[2] + ph[3] + ph[4];
+          std::fprintf(stderr,
+                       "[trace] visit phases (shader clocks/visit): loads %.0f reduce+barrier %.0f "
+                       "math %.0f stores %.0f closing barrier %.0f | total %.0f; visits %.0f, "
+                       "%.1f%% with update\n",
+                       ph[0] / ph[5], ph[1] / ph[5], ph[2] / ph[5], ph[3] / ph[5], ph[4] / ph[5],
+                       tot / ph[5], ph[5], 100 * ph[6] / ph[5]);
+        }
       }
 
       unsigned long long cursor;

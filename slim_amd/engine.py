@@ -13,7 +13,7 @@ import scipy.sparse as sp
 from . import _lib
 from .constants import SLIM_NOPTIONS, SLIM_OK, Opt
 
-KERNEL_AUTO, KERNEL_WAVE_LDS, KERNEL_WAVE_HBM, KERNEL_TILE = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_WAVE_LDS, KERNEL_WAVE_HBM, KERNEL_TILE, KERNEL_TILE16 = 0, 1, 2, 3, 4
 
 
 def make_options(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=1, col_begin=None,

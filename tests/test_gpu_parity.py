@@ -17,7 +17,8 @@ import scipy.sparse as sp
 import slim_oracle as O
 from slim_amd import SLIM, SLIMatrix, _lib
 from slim_amd.constants import SLIM_NOPTIONS, SLIM_OK, Opt
-from slim_amd.engine import (KERNEL_TILE, KERNEL_WAVE_HBM, KERNEL_WAVE_LDS, DeviceMatrix,
+from slim_amd.engine import (KERNEL_TILE, KERNEL_TILE16, KERNEL_WAVE_HBM, KERNEL_WAVE_LDS,
+                             DeviceMatrix,
                              model_to_scipy)
 
 pytestmark = pytest.mark.gpu
@@ -275,7 +276,8 @@ def test_random_ratings(kernel):
 # Its visiting order (a permutation of the union of 16 active sets) is not the oracle's, so
 # parity is checked at the order-independent level: the reference's own order-to-order
 # envelope at optTol 1e-7, the fixed point at a tight tolerance, optimality conditions.
-def test_tile_kernel_ml100k(ml100k, ml_dev, ml_gpu):
+@pytest.mark.parametrize("KERNEL_TILE", [KERNEL_TILE, KERNEL_TILE16])
+def test_tile_kernel_ml100k(ml100k, ml_dev, ml_gpu, KERNEL_TILE):
     R, T = ml100k
     W, st = ml_dev.learn(seed=1, kernel=KERNEL_TILE)
     cs = ml_dev.column_stats()
