@@ -100,7 +100,9 @@ enum {
                                     outside the range come back empty          */
   SLIM_OPTION_GPU_SEED = 13,     /* seed of the visiting permutation [1]       */
   SLIM_OPTION_GPU_DEVICE = 14,   /* HIP device ordinal [current device]        */
-  SLIM_OPTION_GPU_KERNEL = 15    /* slimgpu_kernel_et [SLIMGPU_KERNEL_AUTO]    */
+  SLIM_OPTION_GPU_KERNEL = 15,   /* slimgpu_kernel_et [SLIMGPU_KERNEL_AUTO]    */
+  SLIM_OPTION_GPU_CLUSTER = 16   /* tile kernels: workgroups sharing one tile,
+                                    1/2/4/8 [auto: by tiles per CU]            */
 };
 
 typedef enum {

@@ -43,6 +43,7 @@ class Opt(enum.IntEnum):
     GPU_SEED = 13       # seed of the per-sweep visiting permutation (default 1)
     GPU_DEVICE = 14     # HIP device ordinal (default: current device)
     GPU_KERNEL = 15     # kernel selection, see slim_gpu.h (default auto)
+    GPU_CLUSTER = 16    # tile kernels: workgroups per tile (default auto)
 
 
 for _o in Opt:

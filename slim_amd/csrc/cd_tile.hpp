@@ -40,6 +40,20 @@
 //
 // x is kept dense and interleaved too, x[item][P], with -inf marking "not in
 // this problem's active set".
+//
+// Clusters.  A tile's critical path is (sweeps of its slowest problem) x (time of
+// one sweep on one CU); the most popular items need ~4x the median sweeps, so with
+// few tiles per CU a launch waits for one workgroup.  K = 1, 2, 4 or 8 workgroups
+// (a cluster) can therefore share a tile: the USERS are split into K ranges of equal
+// nnz, member k keeps only its range of r and walks only its slice of every column
+// (csplit[i][k] .. csplit[i][k+1], precomputed), and the P partial dots are summed
+// over the cluster once per visit with a tagged-granule exchange through HBM
+// (8-byte {epoch, value} words written by one write-through store each and polled
+// until every tag shows the visit's epoch -- placement-independent, no fences; see
+// MI355X guide "R2").  Every member then evaluates the same updates on its own
+// copy of x, so members stay in lock-step without further communication.  All
+// spins are bounded: a member that waits longer than ~10 s raises the abort flag
+// and the launch ends with an error instead of hanging the GPU.
 #pragma once
 #include <type_traits>
 
@@ -53,6 +67,16 @@ __device__ __forceinline__ bool tile_active(float xv) { return xv > -3.0e38f; }
 
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(int& v) { asm volatile("" : "+v"(v)); }
+
+typedef unsigned long long tile_gran_t;
+
+__device__ __forceinline__ void gran_store(tile_gran_t* p, uint32_t epoch, float v) {
+  __hip_atomic_store(p, ((tile_gran_t)epoch << 32) | (tile_gran_t)__float_as_uint(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ tile_gran_t gran_load(const tile_gran_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // PROFILE adds s_memtime stamps around the phases of a visit (SLIM_GPU_TRACE=2); the
 // waits it needs perturb the schedule a little, so it is a separate instantiation.
@@ -69,6 +93,8 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
   __shared__ int s_item[P];
   __shared__ int s_na[P];
   __shared__ int s_grp, s_nunion;
+  __shared__ float s_tot[2][P];
+  __shared__ int s_abort;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -77,21 +103,91 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
   const int slot = lane >> LOGP; // which user of a wavefront step
   const uint64_t lane_lt = (1ull << lane) - 1ull;
 
-  float* __restrict__ r = S.slab + (int64_t)blockIdx.x * S.slab_stride;   // [nrows][P]
-  float* __restrict__ x = S.xslab + (int64_t)blockIdx.x * S.x_stride;     // [ncols][P]
+  // cluster geometry: K consecutive workgroups share tiles, member mk owns users
+  // [ubase, uend)
+  const int K = S.cluster;
+  const int cid = (int)blockIdx.x / K, mk = (int)blockIdx.x % K;
+  const int ubase = S.ubounds[mk], uend = S.ubounds[mk + 1];
+  tile_gran_t* const mbox = S.mailbox + (int64_t)cid * (2 * 8 * P + 8);
+  float* aty_sh = S.atyshared ? S.atyshared + (int64_t)cid * S.x_stride : nullptr;  // cluster aTy
+  uint32_t epoch = 0;
+  if (tid == 0) s_abort = 0;
+  float* __restrict__ r = S.slab + (int64_t)blockIdx.x * S.slab_stride;   // [my users][P]
+  float* x = S.xslab + (int64_t)blockIdx.x * S.x_stride;                 // [ncols][P]
   int* __restrict__ ul = S.ulist + (int64_t)blockIdx.x * S.u_stride;      // union list
   const int64_t* __restrict__ colptr = A.colptr;
+  const int64_t* __restrict__ csplit = S.csplit;  // [ncols][K+1] slice boundaries
   const int32_t* __restrict__ ci = A.colind;
   const float* __restrict__ cv = A.colval;
 
   const int nrows = A.nrows, ncols = A.ncols;
   const float l1 = S.l1, l2 = S.l2;
 
-  for (;;) {
-    if (tid == 0) s_grp = atomicAdd(S.queue, 1);
+  // bounded wait for one granule of the current epoch (wave 0 only)
+  auto wait_gran = [&](const tile_gran_t* p, const uint32_t ep) -> float {
+    tile_gran_t g = gran_load(p);
+    if ((uint32_t)(g >> 32) != ep && s_abort == 0) {
+      const uint64_t t0 = wall_clock64();
+      for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        g = gran_load(p);
+        if ((uint32_t)(g >> 32) == ep) break;
+        if (wall_clock64() - t0 > 1000000000ull) {  // 10 s at 100 MHz: give up, loudly
+          s_abort = 1;
+          atomicExch(S.overflow, 2);
+          break;
+        }
+      }
+    }
+    return __uint_as_float((uint32_t)g);
+  };
+  // sum over the cluster of a per-problem value (identical in every lane serving q);
+  // called by all threads of all members at the same points of the program
+  auto cluster_sum = [&](const float v) -> float {
+    if (K == 1) return v;
+    ++epoch;
+    if (epoch == 0) epoch = 1;
+    const int par = (int)(epoch & 1u);
+    if (wave == 0) {
+      if (lane < P) gran_store(mbox + (par * 8 + mk) * P + lane, epoch, v);
+      // lanes [0,32) read the even members, lanes [32,64) the odd ones (P = 32);
+      // for P = 16 four lane groups take members 0,1,2,3 mod 4
+      float tot = 0.0f;
+      for (int kk = slot; kk < K; kk += SL) tot += wait_gran(mbox + (par * 8 + kk) * P + q, epoch);
+      if (SL == 4) tot += __shfl_xor(tot, 16);
+      tot += __shfl_xor(tot, 32);
+      if (lane < P) s_tot[par][q] = tot;
+    }
     __syncthreads();
-    const int grp = s_grp;
-    if (grp >= S.ngroups) break;
+    return s_tot[par][q];
+  };
+  // cluster-wide barrier that also publishes this member's plain stores / atomics
+  auto cluster_barrier = [&]() {
+    if (K == 1) {
+      __syncthreads();
+      return;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    (void)cluster_sum(0.0f);
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+  };
+
+  for (;;) {
+    // member 0 pulls the next tile and tells the others
+    if (tid == 0) {
+      int gnext = 0;
+      if (mk == 0) gnext = atomicAdd(S.queue, 1);
+      s_grp = gnext;
+    }
+    __syncthreads();
+    const int grp = (int)(cluster_sum(mk == 0 ? (float)s_grp : 0.0f) + 0.5f);
+    if (grp >= S.ngroups || s_abort) break;
     const uint64_t t_start = wall_clock64();
     const int base = grp * P;
     const int nprob = (S.nwork - base) < P ? (S.nwork - base) : P;
@@ -103,12 +199,18 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     {
       float4* r4 = reinterpret_cast<float4*>(r);
       float4* x4 = reinterpret_cast<float4*>(x);
-      const int64_t nr4 = (int64_t)nrows * (P / 4), nx4 = (int64_t)ncols * (P / 4);
+      const int64_t nr4 = (int64_t)(uend - ubase) * (P / 4), nx4 = (int64_t)ncols * (P / 4);
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int64_t k = tid; k < nr4; k += 1024) r4[k] = z;
       for (int64_t k = tid; k < nx4; k += 1024) x4[k] = z;
+      if (K > 1) {  // each member clears its share of the cluster's aTy accumulator
+        float4* a4 = reinterpret_cast<float4*>(aty_sh);
+        const int64_t lo = nx4 * mk / K, hi = nx4 * (mk + 1) / K;
+        for (int64_t k = lo + tid; k < hi; k += 1024) a4[k] = z;
+      }
     }
-    __syncthreads();
+    cluster_barrier();
+    float* aty = K > 1 ? aty_sh : x;
 
     // -- y scatter + Gram column: wavefront w serves problems w, w+16 (estimate.c:406-421)
     int64_t Gw[PPW];
@@ -118,7 +220,9 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       const int witem = s_item[pq];
       Gw[pp] = 0;
       if (witem >= 0) {
-        const int64_t cs = uni(colptr[witem]), ce = uni(colptr[witem + 1]);
+        // this member's users of the column
+        const int64_t cs = uni(csplit[(int64_t)witem * (K + 1) + mk]);
+        const int64_t ce = uni(csplit[(int64_t)witem * (K + 1) + mk + 1]);
         for (int64_t jb = cs; jb < ce; jb += 64) {
           const int64_t j = jb + lane;
           const bool ok = j < ce;
@@ -126,7 +230,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
           const float v_l = ok ? (HAS_VAL ? cv[j] : 1.0f) : 0.0f;
           const int64_t rs_l = ok ? A.rowptr[u_l] : 0;
           const int64_t re_l = ok ? A.rowptr[u_l + 1] : 0;
-          if (ok) r[(int64_t)u_l * P + pq] = v_l;
+          if (ok) r[(int64_t)(u_l - ubase) * P + pq] = v_l;
           const int cnt = (int)((ce - jb) < 64 ? (ce - jb) : 64);
           for (int k = 0; k < cnt; ++k) {
             const int64_t rs = lane_bcast(rs_l, k), re = lane_bcast(re_l, k);
@@ -134,13 +238,22 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
             Gw[pp] += re - rs;
             for (int64_t e = rs + lane; e < re; e += 64) {
               const float rv = HAS_VAL ? A.rowval[e] : 1.0f;
-              atomicAdd(&x[(int64_t)A.rowind[e] * P + pq], v * rv);
+              atomicAdd(&aty[(int64_t)A.rowind[e] * P + pq], v * rv);
             }
           }
         }
+        if (K > 1 && mk == 0) {  // the counter G of the whole column (member 0 reports it)
+          int64_t gsum = 0;
+          for (int64_t j = uni(colptr[witem]) + lane; j < uni(colptr[witem + 1]); j += 64) {
+            const int u = ci[j];
+            gsum += A.rowptr[u + 1] - A.rowptr[u];
+          }
+          for (int off = 32; off > 0; off >>= 1) gsum += __shfl_xor(gsum, off);
+          Gw[pp] = gsum;
+        }
       }
     }
-    __syncthreads();
+    cluster_barrier();
 
     // -- active sets (estimate.c:433-444): x = 0 for active, -inf for inactive
     {
@@ -148,7 +261,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       for (int64_t idx = tid; idx < n; idx += 1024) {
         const int i = (int)(idx >> LOGP), qq = (int)(idx & (P - 1));
         const int it = s_item[qq];
-        const bool act = it >= 0 && i != it && x[idx] > l1;
+        const bool act = it >= 0 && i != it && aty[idx] > l1;
         x[idx] = act ? 0.0f : kInactive;
         if (act) atomicAdd(&s_na[qq], 1);
       }
@@ -225,8 +338,10 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
 
     // One coordinate: dot for the P problems, update, residual axpy.
     // mode 0: CD visit; mode 1: fold the warm-start coefficients into r (cd.c:108-110)
-    auto visit = [&](const int i, const int64_t s, const int64_t e, const float xi, const float cn,
-                     const float sq, const bool live, float& dlt, const int mode) {
+    // [s, e) is this member's slice of column i, len the length of the whole column
+    auto visit = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
+                     const float xi, const float cn, const float sq, const bool live, float& dlt,
+                     const int mode) {
       const bool part = live && tile_active(xi);
       if (!__any(part)) return;
       constexpr int64_t CH = 64 * NW;  // nnz per workgroup chunk
@@ -240,7 +355,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
         const int64_t left = e - b0;
         nhere = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
         const bool ok = lane < nhere;
-        idreg = ok ? ci[b0 + lane] : 0;
+        idreg = ok ? ci[b0 + lane] - ubase : 0;
         vreg = ok ? (HAS_VAL ? cv[b0 + lane] : 1.0f) : 0.0f;
       };
       // gather the residual lines of the block: STEPS loads per lane in flight
@@ -305,6 +420,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
 #pragma unroll
         for (int w = 0; w < NW; ++w) dot += s_part[buf][w][q];
         buf ^= 1;
+        dot = cluster_sum(dot);
         p2 = tick();
         const float xeff = (xi > kEps || xi < -kEps) ? xi : 0.0f;
         const float num = dot + xeff * sq;
@@ -315,9 +431,9 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
           d = 0.0f;
           nx = xi;
         } else {
-          D_q += e - s;
+          D_q += len;
           dlt += (nx - xi) * (nx - xi);
-          if (d != 0.0f) U_q += e - s;
+          if (d != 0.0f) U_q += len;
         }
       } else {
         d = (part && (xi > kEps || xi < -kEps)) ? xi : 0.0f;
@@ -353,8 +469,9 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       float unused = 0.0f;
       for (int p = 0; p < nunion; ++p) {
         const int i = uni(ul[p]);
-        visit(i, uni(colptr[i]), uni(colptr[i + 1]), x[(int64_t)i * P + q], 0.0f, 0.0f, !done_q,
-              unused, 1);
+        const int64_t* sp = csplit + (int64_t)i * (K + 1);
+        visit(i, uni(sp[mk]), uni(sp[mk + 1]), uni(sp[K]) - uni(sp[0]), x[(int64_t)i * P + q],
+              0.0f, 0.0f, !done_q, unused, 1);
       }
     }
 
@@ -365,7 +482,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
         niters_q = maxit_q + 1;
       }
       const bool live = !done_q;
-      if (!__any(live)) break;
+      if (!__any(live) || s_abort) break;
       float dlt = 0.0f;
       const PermCtx pc = perm_make((uint32_t)nunion, perm_key(S.seed, (uint32_t)grp, (uint32_t)t));
       if (nunion > 0) {
@@ -374,22 +491,25 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
         // current column is processed (values stay in VGPRs until they are consumed)
         int i_n1 = ul[perm_index(pc, 0u)];
         int i_n2 = nunion > 1 ? ul[perm_index(pc, 1u)] : 0;
-        int64_t s_n = colptr[i_n1], e_n = colptr[i_n1 + 1];
+        const int64_t* sp0 = csplit + (int64_t)i_n1 * (K + 1);
+        int64_t s_n = sp0[mk], e_n = sp0[mk + 1], l_n = sp0[K] - sp0[0];
         float xi_n = x[(int64_t)i_n1 * P + q], cn_n = A.cnorm[i_n1], sq_n = A.csq[i_n1];
         for (int p = 0; p < nunion; ++p) {
           const int i = uni(i_n1);
-          const int64_t s = uni(s_n), e = uni(e_n);
+          const int64_t s = uni(s_n), e = uni(e_n), len = uni(l_n);
           const float xi = xi_n, cn = uni(cn_n), sq = uni(sq_n);
           if (p + 1 < nunion) {
             i_n1 = i_n2;
-            s_n = colptr[i_n1];
-            e_n = colptr[i_n1 + 1];
+            const int64_t* spn = csplit + (int64_t)i_n1 * (K + 1);
+            s_n = spn[mk];
+            e_n = spn[mk + 1];
+            l_n = spn[K] - spn[0];
             xi_n = x[(int64_t)i_n1 * P + q];
             cn_n = A.cnorm[i_n1];
             sq_n = A.csq[i_n1];
             if (p + 2 < nunion) i_n2 = ul[perm_index(pc, (uint32_t)(p + 2))];
           }
-          visit(i, s, e, xi, cn, sq, live, dlt, 0);
+          visit(i, s, e, len, xi, cn, sq, live, dlt, 0);
         }
       }
       if (live && dlt < S.opt_tol) {  // cd.c:135-138
@@ -404,7 +524,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     {
       float e2 = 0.0f, reg = 0.0f;
       const int g = wave * SL + slot;
-      for (int u = g; u < nrows; u += NW * SL) {
+      for (int u = g; u < uend - ubase; u += NW * SL) {
         const float rv = r[(int64_t)u * P + q];
         e2 += rv * rv;
       }
@@ -424,19 +544,19 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       }
     }
     __syncthreads();
+    float err_q = 0.0f;  // 1/2 ||r||^2 of problem q over all members' users
+    for (int w = 0; w < NW; ++w) err_q += s_red[0][w][q];
+    err_q = 0.5f * cluster_sum(err_q);
 
-    // -- output: wavefront w compacts problems w, w+16 (estimate.c:492-505)
+    // -- output: wavefront w of member 0 compacts problems w, w+16 (estimate.c:492-505)
 #pragma unroll
     for (int pp = 0; pp < PPW; ++pp) {
       const int pq = wave + pp * NW;
       const int witem = s_item[pq];
-      if (witem < 0) continue;
-      float err = 0.0f, reg = 0.0f;
-      for (int w = 0; w < NW; ++w) {
-        err += s_red[0][w][pq];
-        reg += s_red[1][w][pq];
-      }
-      err *= 0.5f;
+      if (witem < 0 || mk != 0) continue;
+      float reg = 0.0f;
+      for (int w = 0; w < NW; ++w) reg += s_red[1][w][pq];
+      const float err = lane_bcast(err_q, pq);
       int nz = 0;
       for (int ib = 0; ib < ncols; ib += 64) {
         const int i = ib + lane;
@@ -480,7 +600,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
         S.st_obj[witem] = err + reg;
       }
     }
-    if (S.trace != nullptr && tid == 0) {
+    if (S.trace != nullptr && tid == 0 && mk == 0) {
       uint64_t* tr = S.trace + (int64_t)grp * 8;
       tr[0] = t_start;
       tr[1] = t_setup;

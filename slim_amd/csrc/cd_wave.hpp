@@ -73,6 +73,12 @@ struct SolveArgs {
   int64_t u_stride;
   int32_t ngroups;      // tiles of 16 item columns in the work list
   uint64_t* trace;      // optional per-tile timeline (SLIM_GPU_TRACE), 8 words per tile
+  // tile clusters (cd_tile.hpp): K workgroups share a tile, users split in K ranges
+  int32_t cluster;               // K
+  const int32_t* ubounds;        // [K+1] user-range boundaries
+  const int64_t* csplit;         // [ncols][K+1] column slice boundaries (K = 1: colptr pairs)
+  unsigned long long* mailbox;   // per cluster: 2 x 8 x P granules (+8), zeroed per launch
+  float* atyshared;              // per cluster: [ncols][P] aTy accumulator (K > 1)
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;
   int64_t* out_off;

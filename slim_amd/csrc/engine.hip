@@ -43,6 +43,11 @@ struct slimgpu_matrix {
   float* d_cnorm = nullptr;
   float* d_csq = nullptr;
   std::vector<int64_t> h_cost;  // scheduling proxy per column (Gram work G)
+  std::vector<int64_t> h_rowptr;  // host copy, fetched on first clustered solve
+  // column slice boundaries for tile clusters of size K (index log2 K), built on demand
+  int32_t* d_ubounds[4] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t* d_csplit[4] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t max_range_rows[4] = {0, 0, 0, 0};
   double setup_ms = 0;
   int num_cus = 256;
   // workspace reused by successive solves
@@ -51,7 +56,8 @@ struct slimgpu_matrix {
     size_t bytes = 0;
   };
   Buf ws_order, ws_cnt, ws_off, ws_stat_i, ws_stat_l, ws_stat_f, ws_misc, ws_arena_i, ws_arena_v,
-      ws_slab, ws_xslab, ws_ulist, ws_trace, ws_icolptr, ws_icolind, ws_icolval;
+      ws_slab, ws_xslab, ws_ulist, ws_trace, ws_mailbox, ws_atysh, ws_icolptr, ws_icolind,
+      ws_icolval;
 };
 
 namespace slimamd {
@@ -189,6 +195,28 @@ __global__ void k_col_scalars(int32_t ncols, const int64_t* __restrict__ colptr,
   }
 }
 
+// csplit[c][j] = first position of column c whose user id is >= ubounds[j]
+__global__ void k_col_split(int32_t ncols, int32_t K, const int32_t* __restrict__ ubounds,
+                            const int64_t* __restrict__ colptr,
+                            const int32_t* __restrict__ colind, int64_t* __restrict__ csplit) {
+  const int64_t n = (int64_t)ncols * (K + 1);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t c = (int32_t)(t / (K + 1)), j = (int32_t)(t % (K + 1));
+    int64_t lo = colptr[c], hi = colptr[c + 1];
+    if (j == K) {
+      lo = hi;
+    } else if (j > 0) {
+      const int32_t ub = ubounds[j];
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (colind[mid] < ub) lo = mid + 1; else hi = mid;
+      }
+    }
+    csplit[t] = lo;
+  }
+}
+
 int grid_for(int64_t n, int block, int cap_blocks) {
   int64_t g = (n + block - 1) / block;
   if (g < 1) g = 1;
@@ -268,6 +296,39 @@ void build_column_view(slimgpu_matrix* m) {
   HIP_TRY(hipFree(d_cost));
 }
 
+// user ranges of equal nnz + per-column slice boundaries for clusters of size K = 1 << lg
+void ensure_cluster_split(slimgpu_matrix* m, int lg) {
+  if (m->d_csplit[lg]) return;
+  const int K = 1 << lg;
+  std::vector<int32_t> ub((size_t)K + 1, 0);
+  ub[K] = m->nrows;
+  if (K > 1) {
+    if (m->h_rowptr.empty()) {
+      m->h_rowptr.resize((size_t)m->nrows + 1);
+      HIP_TRY(hipMemcpy(m->h_rowptr.data(), m->d_rowptr, sizeof(int64_t) * ((size_t)m->nrows + 1),
+                        hipMemcpyDeviceToHost));
+    }
+    for (int j = 1; j < K; ++j) {
+      const int64_t want = m->nnz / K * j;
+      ub[j] = (int32_t)(std::lower_bound(m->h_rowptr.begin(), m->h_rowptr.end(), want) -
+                        m->h_rowptr.begin());
+      ub[j] = std::min(std::max(ub[j], ub[j - 1]), m->nrows);
+    }
+  }
+  int32_t mx = 1;
+  for (int j = 0; j < K; ++j) mx = std::max(mx, ub[j + 1] - ub[j]);
+  m->max_range_rows[lg] = mx;
+  m->d_ubounds[lg] = dev_alloc<int32_t>((size_t)K + 1);
+  HIP_TRY(hipMemcpy(m->d_ubounds[lg], ub.data(), sizeof(int32_t) * ((size_t)K + 1),
+                    hipMemcpyHostToDevice));
+  m->d_csplit[lg] = dev_alloc<int64_t>((size_t)m->ncols * (K + 1));
+  hipLaunchKernelGGL(k_col_split, dim3(grid_for((int64_t)m->ncols * (K + 1), 256, m->num_cus * 8)),
+                     dim3(256), 0, m->stream, m->ncols, K, m->d_ubounds[lg], m->d_colptr,
+                     m->d_colind, m->d_csplit[lg]);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(m->stream));
+}
+
 void destroy(slimgpu_matrix* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
@@ -281,10 +342,14 @@ void destroy(slimgpu_matrix* m) {
   (void)hipFree(m->d_colval);
   (void)hipFree(m->d_cnorm);
   (void)hipFree(m->d_csq);
+  for (int k = 0; k < 4; ++k) {
+    (void)hipFree(m->d_ubounds[k]);
+    (void)hipFree(m->d_csplit[k]);
+  }
   for (slimgpu_matrix::Buf* b :
        {&m->ws_order, &m->ws_cnt, &m->ws_off, &m->ws_stat_i, &m->ws_stat_l, &m->ws_stat_f,
         &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_xslab, &m->ws_ulist,
-        &m->ws_trace, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval})
+        &m->ws_trace, &m->ws_mailbox, &m->ws_atysh, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval})
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -314,6 +379,7 @@ LearnOptions decode_options(const int32_t* io, const double* dopt) {
   o.seed = (uint32_t)geti(SLIM_OPTION_GPU_SEED, 1);
   o.device = geti(SLIM_OPTION_GPU_DEVICE, -1);
   o.kernel = geti(SLIM_OPTION_GPU_KERNEL, SLIMGPU_KERNEL_AUTO);
+  o.cluster = geti(SLIM_OPTION_GPU_CLUSTER, 0);
   return o;
 }
 
@@ -549,20 +615,33 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     }
     // wave kernels: one block = one wavefront; tile kernel: one block = 16 wavefronts
     int nwaves = std::max(1, std::min(nwork, m->num_cus * waves_per_cu));
-    const int tile_wgs_per_cu = 1;
     size_t tile_r = 0, tile_x = 0, tile_u = 0;
+    int clusterK = 1, cluster_lg = 0, nclusters = 0;
     if (use_tile) {
-      tile_r = (size_t)nrows_pad * tileP;
+      const int ngroups_all = (nwork + tileP - 1) / tileP;
+      // cluster size: share a tile among K workgroups when there are too few tiles to keep
+      // every CU busy behind the slowest one (auto), or as requested
+      if (opt.cluster == 1 || opt.cluster == 2 || opt.cluster == 4 || opt.cluster == 8) {
+        clusterK = opt.cluster;
+      } else {
+        while (clusterK < 8 && ngroups_all < 3 * (m->num_cus / clusterK)) clusterK *= 2;
+      }
+      while (clusterK > 1 && m->num_cus / clusterK < 1) clusterK /= 2;
+      for (cluster_lg = 0; (1 << cluster_lg) < clusterK; ++cluster_lg) {}
+      ensure_cluster_split(m, cluster_lg);
+      tile_r = (size_t)round_up(m->max_range_rows[cluster_lg], 64) * tileP;
       tile_x = (size_t)ncols_pad * tileP;
       tile_u = (size_t)ncols_pad;
-      const int ngroups_all = (nwork + tileP - 1) / tileP;
-      nwaves = std::max(1, std::min(ngroups_all, m->num_cus * tile_wgs_per_cu));
+      nclusters = std::max(1, std::min(ngroups_all, m->num_cus / clusterK));
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-      const size_t per_wg = (tile_r + tile_x) * sizeof(float) + tile_u * sizeof(int32_t);
-      const size_t have = free_b + m->ws_slab.bytes + m->ws_xslab.bytes + m->ws_ulist.bytes;
+      const size_t per_cl = ((tile_r + tile_x) * sizeof(float) + tile_u * sizeof(int32_t)) * clusterK +
+                            (clusterK > 1 ? tile_x * sizeof(float) : 0);
+      const size_t have = free_b + m->ws_slab.bytes + m->ws_xslab.bytes + m->ws_ulist.bytes +
+                          m->ws_atysh.bytes;
       const size_t budget = have > (size_t(6) << 30) ? have - (size_t(6) << 30) : have / 2;
-      if ((size_t)nwaves * per_wg > budget) nwaves = (int)std::max<size_t>(1, budget / per_wg);
+      if ((size_t)nclusters * per_cl > budget) nclusters = (int)std::max<size_t>(1, budget / per_cl);
+      nwaves = nclusters * clusterK;  // workgroups launched
     }
 
     // device buffers
@@ -577,10 +656,15 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     float* d_slab = nullptr;
     float* d_xslab = nullptr;
     int32_t* d_ulist = nullptr;
+    unsigned long long* d_mailbox = nullptr;
+    float* d_atysh = nullptr;
+    const size_t mailbox_words = (size_t)std::max(nclusters, 1) * (2 * 8 * (size_t)tileP + 8);
     if (use_tile) {
       d_slab = ws_get<float>(m->ws_slab, tile_r * (size_t)nwaves);
       d_xslab = ws_get<float>(m->ws_xslab, tile_x * (size_t)nwaves);
       d_ulist = ws_get<int32_t>(m->ws_ulist, tile_u * (size_t)nwaves);
+      d_mailbox = ws_get<unsigned long long>(m->ws_mailbox, mailbox_words);
+      if (clusterK > 1) d_atysh = ws_get<float>(m->ws_atysh, tile_x * (size_t)nclusters);
     } else if (!use_lds) {
       d_slab = ws_get<float>(m->ws_slab, vec_floats * (size_t)nwaves);
     }
@@ -677,6 +761,13 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.ulist = d_ulist;
       S.u_stride = (int64_t)tile_u;
       S.ngroups = (npend + tileP - 1) / tileP;
+      S.cluster = clusterK;
+      S.ubounds = use_tile ? m->d_ubounds[cluster_lg] : nullptr;
+      S.csplit = use_tile ? m->d_csplit[cluster_lg] : nullptr;
+      S.mailbox = d_mailbox;
+      S.atyshared = d_atysh;
+      if (use_tile)
+        HIP_TRY(hipMemsetAsync(d_mailbox, 0, sizeof(unsigned long long) * mailbox_words, stream));
       const bool trace = use_tile && trace_level >= 1;
       S.trace = nullptr;
       if (trace) {
@@ -699,8 +790,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.st_err = d_stf;
       S.st_obj = d_stf + ncols;
 
+      // clustered tiles: always launch whole clusters (every member must be resident)
       const int launch_waves =
-          std::max(1, std::min(use_tile ? (npend + tileP - 1) / tileP : npend, nwaves));
+          use_tile ? std::max(1, std::min((npend + tileP - 1) / tileP, nclusters)) * clusterK
+                   : std::max(1, std::min(npend, nwaves));
       HIP_TRY(hipEventRecord(ev0, stream));
       hipLaunchKernelGGL(fn, dim3(launch_waves), dim3(use_tile ? 64 * kTileNW : 64),
                          use_lds ? lds_need : 0, stream, A, S);
@@ -735,11 +828,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         std::sort(dur.begin(), dur.end());
         const double span = double(t1 - t0);
         std::fprintf(stderr,
-                     "[trace] tiles %d on %d workgroups: span %.2f ms (event %.2f ms), busy/"
+                     "[trace] tiles %d on %d workgroups (clusters of %d): span %.2f ms (event %.2f ms), busy/"
                      "(span*wgs) %.2f, setup %.1f%% sweeps %.1f%% of busy; tile ms min %.2f med "
                      "%.2f p90 %.2f max %.2f\n",
-                     S.ngroups, launch_waves, span * 1e-5, ms,
-                     busy / (span * launch_waves), 100 * setup / busy, 100 * sweeps / busy,
+                     S.ngroups, launch_waves, clusterK, span * 1e-5, ms,
+                     busy * clusterK / (span * launch_waves), 100 * setup / busy, 100 * sweeps / busy,
                      dur.front(), dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back());
         if (trace_level >= 2) {
           double ph[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -755,6 +848,13 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         }
       }
 
+      if (h_misc[1] == 2) {
+        set_error("SLIMGPU_Learn: a tile cluster timed out waiting for a member workgroup "
+                  "(were all workgroups resident?)");
+        HIP_TRY(hipEventDestroy(ev0));
+        HIP_TRY(hipEventDestroy(ev1));
+        return fail(SLIM_ERROR);
+      }
       unsigned long long cursor;
       std::memcpy(&cursor, h_misc + 2, sizeof(cursor));
       const int64_t used = std::min<int64_t>((int64_t)cursor, arena_cap);

@@ -17,6 +17,7 @@ struct LearnOptions {
   uint32_t seed = 1;
   int32_t device = -1;  // -1: current
   int32_t kernel = SLIMGPU_KERNEL_AUTO;
+  int32_t cluster = 0;  // tile-cluster size (0 = auto)
 };
 LearnOptions decode_options(const int32_t* ioptions, const double* doptions);
 

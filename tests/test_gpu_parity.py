@@ -276,9 +276,16 @@ def test_random_ratings(kernel):
 # Its visiting order (a permutation of the union of 16 active sets) is not the oracle's, so
 # parity is checked at the order-independent level: the reference's own order-to-order
 # envelope at optTol 1e-7, the fixed point at a tight tolerance, optimality conditions.
-@pytest.mark.parametrize("KERNEL_TILE", [KERNEL_TILE, KERNEL_TILE16])
-def test_tile_kernel_ml100k(ml100k, ml_dev, ml_gpu, KERNEL_TILE):
+@pytest.mark.parametrize("KERNEL_TILE,cluster", [(KERNEL_TILE, 1), (KERNEL_TILE, 8),
+                                                 (KERNEL_TILE, 2), (KERNEL_TILE16, 1),
+                                                 (KERNEL_TILE16, 4)])
+def test_tile_kernel_ml100k(ml100k, ml_dev, ml_gpu, KERNEL_TILE, cluster):
+    """cluster = workgroups sharing one tile (users split in `cluster` ranges, one
+    all-reduce of the partial dots per visit)."""
     R, T = ml100k
+    import functools
+    ml_dev = type("M", (), {"learn": staticmethod(functools.partial(ml_dev.learn, cluster=cluster)),
+                            "column_stats": staticmethod(ml_dev.column_stats)})()
     W, st = ml_dev.learn(seed=1, kernel=KERNEL_TILE)
     cs = ml_dev.column_stats()
     assert st["kernel"] == KERNEL_TILE
@@ -316,11 +323,19 @@ def test_tile_kernel_ratings_and_warm_start():
     Wr = O.learn_cd(R, order=O.ORDER_PERM, aty=O.ATY_GRAM, nthreads=8, optTol=1e-13,
                     maxniters=100000)
     assert maxdiff(Wt, Wr) <= 2e-5
-    # warm start through the tile kernel
-    first, _ = m.learn(l1r=3.0, l2r=1.0, optTol=1e-13, niters=100000)
-    warm, st_w = m.learn(l1r=1.0, l2r=1.0, optTol=1e-13, niters=100000, imodel=first)
-    cold_sweeps = m.learn(l1r=1.0, l2r=1.0, optTol=1e-13, niters=100000)[1]["sweeps"]
-    assert maxdiff(warm, Wr) <= 2e-5 and st_w["sweeps"] < cold_sweeps
+    # warm start through the tile kernel, alone and in clusters of 4 workgroups
+    for cl in (1, 4):
+        first, _ = m.learn(l1r=3.0, l2r=1.0, optTol=1e-13, niters=100000, cluster=cl)
+        warm, st_w = m.learn(l1r=1.0, l2r=1.0, optTol=1e-13, niters=100000, imodel=first,
+                             cluster=cl)
+        cold_sweeps = m.learn(l1r=1.0, l2r=1.0, optTol=1e-13, niters=100000,
+                              cluster=cl)[1]["sweeps"]
+        assert maxdiff(warm, Wr) <= 2e-5 and st_w["sweeps"] < cold_sweeps
+    # cluster sizes agree with each other on everything that is order-independent
+    W8, st8 = m.learn(l1r=1.0, l2r=1.0, seed=2, cluster=8)
+    assert maxdiff(W8, Wo) <= 3e-3 and abs(st8["objval"] - obj) <= 1e-4 * obj
+    cs8 = m.column_stats()
+    assert np.array_equal(cs8.nacols, so["nacols"]) and np.array_equal(cs8.G, so["G"])
     m.close()
 
 
