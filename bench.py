@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s HBM3E 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("SLIM_BENCH_WORKLOAD", "c4"),
                     help="c4 | c4-0.1pct | c5 | ml100k")
@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ratings", action="store_true", help="ratings 1..5 instead of binary values")
     ap.add_argument("--kernel", type=int, default=0, help="slimgpu_kernel_et (0 = auto)")
+    ap.add_argument("--cluster", type=int, default=int(os.environ.get("SLIM_BENCH_CLUSTER", "0")),
+                    help="tile kernels: workgroups per tile, 1/2/4/8 (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="CPU-baseline budget (0 disables the leg)")
     ap.add_argument("--replicate", default="broadcast", choices=["broadcast", "generate"])
@@ -112,9 +114,11 @@ def main():
 
     blocks = partition_columns(mat.column_cost(), world)
     cb, ce = blocks[rank]
-    batch = args.batch or (ncols if args.workload == "ml100k" else 2048)
+    batch = args.batch or (ncols if args.workload == "ml100k" else 8192)
     batch = max(1, min(batch, ce - cb))
     opts = dict(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=args.seed, kernel=args.kernel)
+    if args.cluster:
+        opts["cluster"] = args.cluster
 
     def step(i):
         """Solve batch i of this rank's block; with N > 1 also gather the learned columns."""

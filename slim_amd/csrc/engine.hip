@@ -624,7 +624,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       if (opt.cluster == 1 || opt.cluster == 2 || opt.cluster == 4 || opt.cluster == 8) {
         clusterK = opt.cluster;
       } else {
-        while (clusterK < 8 && ngroups_all < 3 * (m->num_cus / clusterK)) clusterK *= 2;
+        // the heaviest tile runs ~7x the median (popular items need more sweeps): a
+        // cluster should see >= ~8 tiles so the others fill in behind it; with fewer
+        // tiles per cluster, larger clusters shorten that critical path instead
+        while (clusterK < 8 && (int64_t)ngroups_all * clusterK < 8 * (int64_t)m->num_cus)
+          clusterK *= 2;
       }
       while (clusterK > 1 && m->num_cus / clusterK < 1) clusterK /= 2;
       for (cluster_lg = 0; (1 << cluster_lg) < clusterK; ++cluster_lg) {}
