@@ -584,6 +584,189 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
   return ncols;
 }
 
+/* ------------------------------------------------------------------------ */
+/* EstimateModelCD in the visiting order of the engine's tile kernel          */
+/* ------------------------------------------------------------------------ */
+/* slim_amd/csrc/cd_tile.hpp solves `tileP` item columns per workgroup in
+ * lock-step: tile g = entries [g*tileP, (g+1)*tileP) of the work list `order`
+ * (the engine sorts the requested columns by descending Gram work G, stable);
+ * sweep t of the tile walks u[perm(p; key(seed, g, t))], p = 0..|u|-1, where u
+ * is the ascending union of the members' active sets, and each member skips
+ * the coordinates outside its own active set.  Per member the algorithm is
+ * EstimateModelCD/CoordinateDescent unchanged (reference arithmetic: fp64,
+ * 3-pass), so this is the same restatement with a different ShuffleList.     */
+int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
+                             const int32_t *rowind, const float *rowval,
+                             const oracle_cfg_t *cfg, int32_t tileP,
+                             int32_t nwork, const int32_t *order,
+                             int64_t **r_colptr, int32_t **r_colind,
+                             float **r_colval, oracle_colstat_t *stats,
+                             double *r_error, double *r_objval) {
+  const int64_t nnz = rowptr[nrows];
+  const int32_t ncols = oracle_ncols(nnz, rowind);
+  if (ncols <= 0 || tileP <= 0) return -1;
+  int64_t *colptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)ncols + 1));
+  int32_t *colind = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+  float *colval =
+      rowval ? (float *)malloc(sizeof(float) * (size_t)(nnz ? nnz : 1)) : NULL;
+  float *cnorms = (float *)malloc(sizeof(float) * (size_t)ncols);
+  oracle_transpose(nrows, ncols, rowptr, rowind, rowval, colptr, colind, colval);
+  oracle_col_norms(ncols, colptr, colval, cnorms);
+  cview_t A = {colptr, colind, colval, cnorms};
+  int32_t *nnzs = (int32_t *)calloc((size_t)ncols, sizeof(int32_t));
+  fkv_t **lists = (fkv_t **)calloc((size_t)ncols, sizeof(fkv_t *));
+  double error = 0.0, objval = 0.0;
+  if (stats) memset(stats, 0, sizeof(oracle_colstat_t) * (size_t)ncols);
+  const int32_t ntiles = (nwork + tileP - 1) / tileP;
+  int nthreads = cfg->nthreads > 0 ? cfg->nthreads : 1;
+
+#pragma omp parallel num_threads(nthreads) reduction(+ : error, objval)
+  {
+    double *x = (double *)calloc((size_t)ncols, sizeof(double));
+    double *y = (double *)calloc((size_t)nrows, sizeof(double));
+    double *yhat = (double *)calloc((size_t)nrows, sizeof(double));
+    double *ATy = (double *)calloc((size_t)ncols, sizeof(double));
+    float *key = (float *)malloc(sizeof(float) * (size_t)ncols * (size_t)tileP);
+    uint8_t *act = (uint8_t *)malloc((size_t)ncols * (size_t)tileP);
+    int32_t *uni = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
+    int64_t *Gm = (int64_t *)malloc(sizeof(int64_t) * (size_t)tileP);
+
+#pragma omp for schedule(dynamic, 1)
+    for (int32_t g = 0; g < ntiles; g++) {
+      const int32_t base = g * tileP;
+      const int32_t np = (nwork - base) < tileP ? (nwork - base) : tileP;
+      /* active sets of the members (estimate.c:406-444, Gram-column aTy) */
+      memset(act, 0, (size_t)ncols * (size_t)tileP);
+      for (int32_t m = 0; m < np; m++) {
+        const int32_t iC = order[base + m];
+        Gm[m] = 0;
+        for (int64_t j = colptr[iC]; j < colptr[iC + 1]; j++) {
+          const int32_t u = colind[j];
+          const double v = colval ? colval[j] : 1.0;
+          for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++)
+            ATy[rowind[e]] += v * (rowval ? rowval[e] : 1.0);
+          Gm[m] += rowptr[u + 1] - rowptr[u];
+        }
+        for (int32_t i = 0; i < ncols; i++) {
+          if (ATy[i] > cfg->l1r && i != iC) {
+            act[(size_t)m * ncols + i] = 1;
+            key[(size_t)m * ncols + i] = (float)ATy[i];
+          }
+        }
+        for (int64_t j = colptr[iC]; j < colptr[iC + 1]; j++) {
+          const int32_t u = colind[j];
+          for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++) ATy[rowind[e]] = 0.0;
+        }
+      }
+      int32_t nu = 0;
+      for (int32_t i = 0; i < ncols; i++) {
+        int any = 0;
+        for (int32_t m = 0; m < np; m++) any |= act[(size_t)m * ncols + i];
+        if (any) uni[nu++] = i;
+      }
+      /* every member: CoordinateDescent (cd.c:101-142) in the tile's order */
+      for (int32_t m = 0; m < np; m++) {
+        const int32_t iC = order[base + m];
+        const uint8_t *am = act + (size_t)m * ncols;
+        const float *km = key + (size_t)m * ncols;
+        const int64_t cs = colptr[iC], ce = colptr[iC + 1];
+        int64_t D = 0, U = 0;
+        int32_t na = 0;
+        for (int32_t k = 0; k < nu; k++) na += am[uni[k]];
+        for (int64_t j = cs; j < ce; j++) y[colind[j]] = colval ? colval[j] : 1.0;
+        int64_t cap = 50 * (ce - cs);
+        int32_t maxit = cap < cfg->maxniters ? (int32_t)cap : cfg->maxniters;
+        int32_t t, rstatus = 0;
+        for (t = 0; t < maxit; t++) {
+          double dltx = 0.0;
+          uint32_t pk = oracle_perm_key(cfg->seed, (uint32_t)g, (uint32_t)t);
+          for (int32_t p = 0; p < nu; p++) {
+            const int32_t iI = uni[oracle_perm_index((uint32_t)p, (uint32_t)nu, pk)];
+            if (!am[iI]) continue;
+            const double aTy = km[iI], aTa = cnorms[iI], xi = x[iI];
+            const int64_t len = colptr[iI + 1] - colptr[iI];
+            int64_t touched = add_spvec(&A, iI, -xi, yhat);
+            const double ip = spvec_dot(&A, iI, yhat);
+            const double num = aTy - ip;
+            const double newxi =
+                num > cfg->l1r ? (num - cfg->l1r) / ((aTa * aTa) + cfg->l2r) : 0.0;
+            touched += add_spvec(&A, iI, newxi, yhat);
+            x[iI] = newxi;
+            dltx += (newxi - xi) * (newxi - xi);
+            D += len;
+            if (touched) U += len;
+          }
+          if (dltx < cfg->optTol) {
+            rstatus = 1;
+            break;
+          }
+        }
+        const int32_t niters = t + 1;
+        double rn = 0.0;
+        for (int32_t i = 0; i < nrows; i++) rn += (y[i] - yhat[i]) * (y[i] - yhat[i]);
+        rn *= 0.5;
+        double ob = rn;
+        int32_t nz = 0;
+        for (int32_t k = 0; k < nu; k++) {
+          const double xv = x[uni[k]];
+          ob += 0.5 * cfg->l2r * xv * xv + cfg->l1r * fabs(xv);
+          if (fabs(xv) > ORACLE_EPS) nz++;
+        }
+        error += rn;
+        objval += ob;
+        fkv_t *list = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)(nz ? nz : 1));
+        nz = 0;
+        for (int32_t k = 0; k < nu; k++)
+          if (fabs(x[uni[k]]) > ORACLE_EPS) {
+            list[nz].key = (float)x[uni[k]];
+            list[nz].val = uni[k];
+            nz++;
+          }
+        nnzs[iC] = nz;
+        lists[iC] = list;
+        if (stats) {
+          stats[iC].nacols = na;
+          stats[iC].sweeps = niters;
+          stats[iC].conv = rstatus;
+          stats[iC].nnzw = nz;
+          stats[iC].G = Gm[m];
+          stats[iC].D = D;
+          stats[iC].U = U;
+          stats[iC].err = rn;
+          stats[iC].obj = ob;
+        }
+        for (int64_t j = cs; j < ce; j++) y[colind[j]] = 0.0;
+        for (int32_t k = 0; k < nu; k++) x[uni[k]] = 0.0;
+        memset(yhat, 0, sizeof(double) * (size_t)nrows);
+      }
+    }
+    free(x); free(y); free(yhat); free(ATy); free(key); free(act); free(uni); free(Gm);
+  }
+
+  int64_t tnnz = 0;
+  for (int32_t c = 0; c < ncols; c++) tnnz += nnzs[c];
+  int64_t *wptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)ncols + 1));
+  int32_t *wind = (int32_t *)malloc(sizeof(int32_t) * (size_t)(tnnz ? tnnz : 1));
+  float *wval = (float *)malloc(sizeof(float) * (size_t)(tnnz ? tnnz : 1));
+  wptr[0] = 0;
+  tnnz = 0;
+  for (int32_t c = 0; c < ncols; c++) {
+    for (int32_t k = 0; k < nnzs[c]; k++, tnnz++) {
+      wind[tnnz] = (int32_t)lists[c][k].val;
+      wval[tnnz] = lists[c][k].key;
+    }
+    wptr[c + 1] = tnnz;
+    free(lists[c]);
+  }
+  free(lists); free(nnzs); free(colptr); free(colind); free(colval); free(cnorms);
+  *r_colptr = wptr;
+  *r_colind = wind;
+  *r_colval = wval;
+  if (r_error) *r_error = error;
+  if (r_objval) *r_objval = objval;
+  return ncols;
+}
+
 void oracle_free(void *p) { free(p); }
 
 /* ------------------------------------------------------------------------ */

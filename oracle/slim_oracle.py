@@ -123,6 +123,55 @@ def learn_cd(R, l1r=1.0, l2r=1.0, optTol=1e-7, maxniters=10000, nthreads=1,
     return W
 
 
+def tile_work_order(R, col_begin=0, col_end=None):
+    """The engine's work list for a column range: descending Gram work G (sum over the
+    column's users of their row lengths), stable (slim_amd/csrc/engine.hip::learn_cd)."""
+    R = sp.csr_matrix(R)
+    Rc = R.tocsc()
+    deg = np.diff(R.indptr).astype(np.int64)
+    ncols = int(R.indices.max()) + 1 if R.nnz else 0
+    G = np.zeros(ncols, np.int64)
+    colof = np.repeat(np.arange(Rc.shape[1]), np.diff(Rc.indptr))
+    np.add.at(G, colof, deg[Rc.indices])
+    col_end = ncols if col_end is None else col_end
+    cols = np.arange(col_begin, col_end)
+    return cols[np.argsort(-G[col_begin:col_end], kind="stable")].astype(np.int32)
+
+
+def learn_cd_tile(R, tileP=32, order=None, l1r=1.0, l2r=1.0, optTol=1e-7, maxniters=10000,
+                  nthreads=1, seed=1, binary=False, return_stats=False):
+    """EstimateModelCD in the tile kernel's visiting order (see oracle_learn_cd_tile)."""
+    L = lib()
+    nrows, ptr, ind, val = _csr_arrays(R, binary)
+    if order is None:
+        order = tile_work_order(R)
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    cfg = Cfg(l1r, l2r, optTol, maxniters, nthreads, ORDER_PERM, seed, ATY_GRAM, 0)
+    ncols = int(ind.max()) + 1 if ind.size else 0
+    stats = np.zeros(ncols, dtype=COLSTAT_DTYPE)
+    wptr, wind, wval = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_float)()
+    err, obj = C.c_double(0), C.c_double(0)
+    L.oracle_learn_cd_tile.restype = C.c_int32
+    n = L.oracle_learn_cd_tile(C.c_int32(nrows), _p(ptr, C.c_int64), _p(ind, C.c_int32),
+                               _p(val, C.c_float), C.byref(cfg), C.c_int32(tileP),
+                               C.c_int32(order.size), _p(order, C.c_int32),
+                               C.byref(wptr), C.byref(wind), C.byref(wval),
+                               stats.ctypes.data_as(C.POINTER(ColStat)),
+                               C.byref(err), C.byref(obj))
+    if n < 0:
+        raise RuntimeError("oracle_learn_cd_tile failed")
+    indptr = np.ctypeslib.as_array(wptr, shape=(n + 1,)).copy()
+    nnz = int(indptr[-1])
+    indices = np.ctypeslib.as_array(wind, shape=(max(nnz, 1),))[:nnz].copy()
+    data = np.ctypeslib.as_array(wval, shape=(max(nnz, 1),))[:nnz].copy()
+    for p in (wptr, wind, wval):
+        L.oracle_free(C.cast(p, C.c_void_p))
+    W = sp.csc_matrix((data, indices, indptr), shape=(n, n))
+    if return_stats:
+        return W, stats, err.value, obj.value
+    return W
+
+
 def _w_rows(W):
     Wr = sp.csr_matrix(W)
     Wr.sort_indices()

@@ -289,6 +289,13 @@ def test_tile_kernel_ml100k(ml100k, ml_dev, ml_gpu, KERNEL_TILE, cluster):
     W, st = ml_dev.learn(seed=1, kernel=KERNEL_TILE)
     cs = ml_dev.column_stats()
     assert st["kernel"] == KERNEL_TILE
+    # visit for visit against the oracle walking the tile order (ORDER_TILE)
+    P = 32 if KERNEL_TILE == globals()["KERNEL_TILE"] else 16
+    Wo, so, err_o, obj_o = O.learn_cd_tile(R, tileP=P, seed=1, nthreads=8, return_stats=True)
+    assert maxdiff(W, Wo) <= 2e-5 and pattern_diff(W, Wo) <= 8
+    assert (cs.sweeps == so["sweeps"]).mean() >= 0.99
+    assert abs(cs.D.sum() - so["D"].sum()) <= 0.01 * so["D"].sum()
+    assert abs(st["objval"] - obj_o) <= 1e-4 * obj_o
     assert maxdiff(W, ml_gpu[0]) <= 3e-3
     assert np.array_equal(cs.nacols, ml_gpu[2].nacols) and np.array_equal(cs.G, ml_gpu[2].G)
     assert abs(st["objval"] - ml_gpu[1]["objval"]) <= 1e-4 * st["objval"]
@@ -316,6 +323,9 @@ def test_tile_kernel_ratings_and_warm_start():
     assert maxdiff(W, Wo) <= 3e-3
     assert abs(st["objval"] - obj) <= 1e-4 * obj and abs(st["error"] - err) <= 1e-4 * err
     cs = m.column_stats()
+    Wtile, stile, _, _ = O.learn_cd_tile(R, tileP=32, seed=2, nthreads=8, return_stats=True)
+    assert maxdiff(W, Wtile) <= 5e-5                      # same visiting order: fp32 vs fp64
+    assert (cs.sweeps == stile["sweeps"]).mean() >= 0.98
     assert np.array_equal(cs.nacols, so["nacols"]) and np.array_equal(cs.G, so["G"])
     Wh, _ = m.learn(l1r=1.0, l2r=1.0, seed=2, kernel=KERNEL_WAVE_HBM)
     assert maxdiff(Wh, Wo) <= 5e-5           # the wave kernel walks the oracle's order
