@@ -94,13 +94,14 @@ def main():
         if rank == 0 or args.replicate == "generate":
             rowptr, rowind, rowval = synth.generate_csr(nrows, ncols, target, seed=args.seed,
                                                         ratings=args.ratings, device=dev)
+            if not args.ratings:
+                rowval = None  # implicit feedback: the C API's rowval == NULL path (4-byte nnz)
         else:
             rowptr = rowind = rowval = None
         if world > 1 and args.replicate == "broadcast":
+            # the one data-path collective before the solve: R from rank 0 to every GPU
             rowptr, rowind, rowval = broadcast_csr(rowptr, rowind, rowval, src=0)
         name = "synthetic %dx%d" % (nrows, ncols)
-    if not args.ratings and args.workload != "ml100k":
-        rowval = None  # implicit feedback: the C API's rowval == NULL path (4-byte nnz)
     nnz = int(rowind.numel())
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
@@ -155,7 +156,9 @@ def main():
     if rank == 0:
         cols_total = world * args.steps * batch
         achieved = acc["alg_bytes"] / (acc["kernel_ms"] * 1e-3) / 1e9 if acc["kernel_ms"] > 0 else 0.0
-        traffic = os.environ.get("SLIM_BENCH_TRAFFIC_BYTES")
+        traffic = os.environ.get("SLIM_BENCH_TRAFFIC_BYTES") or pmc_traffic(
+            args, batch, {0: "auto", 1: "wave-lds", 2: "wave-hbm", 3: "tile32", 4: "tile16"}.get(
+                st["kernel"]), rowval is None)
         out = {
             "metric": "item-columns solved/sec (whole node)",
             "value": cols_total / elapsed,
@@ -197,6 +200,25 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, batch, kernel, binary):
+    """HBM bytes per launch from the PMC counters.  They cannot be collected inside this
+    process (rocprofv3 wraps the whole command, one --pmc pass per counter), so the figure
+    measured for this exact configuration is read from profiles/pmc_traffic.json; any other
+    configuration reports null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            entries = json.load(f)["entries"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for e in entries:
+        m = e["match"]
+        if (m["workload"] == args.workload and float(m["scale"]) == float(args.scale) and
+                m["columns_per_step_per_gpu"] == batch and m["kernel"] == kernel and
+                bool(m["binary"]) == bool(binary)):
+            return e["traffic_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(args, rowptr, rowind, rowval, nrows, ncols, b, batch, opts, W_gpu):

@@ -29,6 +29,22 @@ __global__ __launch_bounds__(1024) void gather(const float* __restrict__ buf, ui
   if (acc == 123.456f) out[0] = acc;
 }
 
+// random whole-granule stores (the update pass of the tile kernel writes whole lines)
+template <int GRAN, int UNROLL>
+__global__ __launch_bounds__(1024) void scatter(float* __restrict__ buf, uint32_t ngran, int iters) {
+  const int lane = threadIdx.x & 63;
+  constexpr int LPG = GRAN / 4;
+  const int grp = lane / LPG, sub = lane % LPG;
+  const uint32_t wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) {
+      uint32_t g = mix(wid * 7919u + (uint32_t)(it * UNROLL + j) * 64u + (uint32_t)grp) % ngran;
+      buf[(size_t)g * LPG + sub] = (float)it;
+    }
+  }
+}
+
 template <int GRAN, int UNROLL>
 void run(const float* buf, size_t bytes, int blocks, int threads, int iters, float* out) {
   uint32_t ngran = (uint32_t)(bytes / GRAN);
@@ -50,6 +66,16 @@ int main(int argc, char** argv) {
   float* buf; CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 0, bytes));
   float* out; CK(hipMalloc(&out, 4));
   int iters = 2000;
+  if (argc > 1 && argv[1][0] == 'c') {
+    // PMC calibration: one gather launch and one scatter launch of exactly known bytes
+    // (256 blocks x 16 waves x iters x 16 x 256 B), random 128-byte lines
+    const int it = 1000;
+    hipLaunchKernelGGL((gather<128, 16>), dim3(256), dim3(1024), 0, 0, buf, (uint32_t)(bytes / 128), it, out);
+    hipLaunchKernelGGL((scatter<128, 16>), dim3(256), dim3(1024), 0, 0, buf, (uint32_t)(bytes / 128), it);
+    CK(hipDeviceSynchronize());
+    printf("calibration: each launch moves %.0f bytes\n", 256.0 * 16 * it * 16 * 256.0);
+    return 0;
+  }
   for (int blocks : {1, 256, 512}) {
     for (int threads : {256, 1024}) {
       run<64, 16>(buf, bytes, blocks, threads, iters, out);

@@ -270,16 +270,66 @@ __global__ __launch_bounds__(64) void cd_wave_kernel(const DevMatrix A, const So
     for (; t < maxit; ++t) {
       float dlt = 0.0f;
       const PermCtx pc = perm_make((uint32_t)na, perm_key(S.seed, (uint32_t)iC, (uint32_t)t));
+      // Software pipeline over the visits of the sweep (every stage is a dependent
+      // memory access of the one before it):
+      //   stage A, 3 visits ahead: slot q = perm(p+3), item id and x from the work vectors
+      //   stage B, 2 visits ahead: column offsets and norms of that item (L2)
+      //   stage C, 1 visit  ahead: the first 128 entries of the column (two per lane)
+      // Slots are visited once per sweep, so an x read ahead cannot be stale; the
+      // pipeline is refilled at every sweep.
+      struct StageB { int64_t s, e; float cn, sq; };
+      auto stage_a = [&](const int pp, int& q, int& i, float& xv) {
+        q = (int)perm_index(pc, (uint32_t)pp);
+        i = ids[q];
+        xv = x[q];
+      };
+      auto stage_b = [&](const int i) -> StageB {
+        StageB b;
+        b.s = A.colptr[i];
+        b.e = A.colptr[i + 1];
+        b.cn = A.cnorm[i];
+        b.sq = A.csq[i];
+        return b;
+      };
+      int qa = 0, ia = 0, qb = 0, ib = 0, qc = 0, ic = 0;
+      float xa = 0.f, xb = 0.f, xc = 0.f;
+      StageB ba = {0, 0, 0.f, 0.f}, bb = {0, 0, 0.f, 0.f};
+      int u0 = 0, u1 = 0;
+      float v0 = 0.f, v1 = 0.f;
+      auto stage_c = [&](const int64_t s, const int64_t e_end) {
+        const int64_t k0 = s + lane, k1 = k0 + 64;
+        u0 = k0 < e_end ? A.colind[k0] : 0;
+        v0 = k0 < e_end ? (HAS_VAL ? A.colval[k0] : 1.0f) : 0.0f;
+        u1 = k1 < e_end ? A.colind[k1] : 0;
+        v1 = k1 < e_end ? (HAS_VAL ? A.colval[k1] : 1.0f) : 0.0f;
+      };
+      if (na > 0) {  // fill: visit 0 fully staged, visit 1 through B, visit 2 through A
+        stage_a(0, qa, ia, xa);
+        ba = stage_b(uni(ia));
+        if (na > 1) {
+          stage_a(1, qb, ib, xb);
+          bb = stage_b(uni(ib));
+        }
+        if (na > 2) stage_a(2, qc, ic, xc);
+        stage_c(uni(ba.s), uni(ba.e));
+      }
       for (int p = 0; p < na; ++p) {
-        const int q = (int)perm_index(pc, (uint32_t)p);
-        const int i = uni(ids[q]);
-        const float xi = uni(x[q]);
-        const int64_t s = uni(A.colptr[i]), e_end = uni(A.colptr[i + 1]);
-        const float cn = uni(A.cnorm[i]);
-        const float sq = uni(A.csq[i]);
+        // the visit being processed
+        const int q = uni(qa);
+        const float xi = uni(xa);
+        const int64_t s = uni(ba.s), e_end = uni(ba.e);
+        const float cn = uni(ba.cn), sq = uni(ba.sq);
+        const int cu0 = u0, cu1 = u1;
+        const float cv0 = v0, cv1 = v1;
+        // advance the pipeline before touching r, so the loads fly under this visit
+        qa = qb; ia = ib; xa = xb; ba = bb;
+        qb = qc; ib = ic; xb = xc;
+        if (p + 1 < na) stage_c(uni(ba.s), uni(ba.e));
+        if (p + 2 < na) bb = stage_b(uni(ib));
+        if (p + 3 < na) stage_a(p + 3, qc, ic, xc);
 
-        float acc = 0.0f;
-        for (int64_t e = s + lane; e < e_end; e += 64) {
+        float acc = cv0 * r[cu0] + cv1 * r[cu1];
+        for (int64_t e = s + 128 + lane; e < e_end; e += 64) {
           const float v = HAS_VAL ? A.colval[e] : 1.0f;
           acc += v * r[A.colind[e]];
         }
@@ -292,7 +342,9 @@ __global__ __launch_bounds__(64) void cd_wave_kernel(const DevMatrix A, const So
         const float d = neff - xeff;
         D += e_end - s;
         if (d != 0.0f) {
-          for (int64_t e = s + lane; e < e_end; e += 64)
+          if (s + lane < e_end) r[cu0] -= d * cv0;
+          if (s + 64 + lane < e_end) r[cu1] -= d * cv1;
+          for (int64_t e = s + 128 + lane; e < e_end; e += 64)
             r[A.colind[e]] -= d * (HAS_VAL ? A.colval[e] : 1.0f);
           U += e_end - s;
           wave_sync<USE_LDS>();
