@@ -126,7 +126,7 @@ def main():
         b = cb + (i * batch) % max(1, (ce - cb) - batch + 1)
         W, st = mat.learn(col_begin=b, col_end=b + batch, **opts)
         if world > 1:
-            W = gather_model(W)
+            W = gather_model(W, dst=0)  # the learned columns end up on rank 0
         return W, st, b
 
     def fence():

@@ -123,26 +123,12 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
   const int nrows = A.nrows, ncols = A.ncols;
   const float l1 = S.l1, l2 = S.l2;
 
-  // bounded wait for one granule of the current epoch (wave 0 only)
-  auto wait_gran = [&](const tile_gran_t* p, const uint32_t ep) -> float {
-    tile_gran_t g = gran_load(p);
-    if ((uint32_t)(g >> 32) != ep && s_abort == 0) {
-      const uint64_t t0 = wall_clock64();
-      for (;;) {
-        __builtin_amdgcn_s_sleep(1);
-        g = gran_load(p);
-        if ((uint32_t)(g >> 32) == ep) break;
-        if (wall_clock64() - t0 > 1000000000ull) {  // 10 s at 100 MHz: give up, loudly
-          s_abort = 1;
-          atomicExch(S.overflow, 2);
-          break;
-        }
-      }
-    }
-    return __uint_as_float((uint32_t)g);
-  };
   // sum over the cluster of a per-problem value (identical in every lane serving q);
-  // called by all threads of all members at the same points of the program
+  // called by all threads of all members at the same points of the program.  Wave 0
+  // publishes this member's P granules, then every lane polls the granules of "its"
+  // members (all loads of a poll round are issued together: one round trip when the
+  // partners have already published) until every tag shows the epoch.  The wait is
+  // bounded: after ~10 s the abort flag is raised and the launch ends with an error.
   auto cluster_sum = [&](const float v) -> float {
     if (K == 1) return v;
     ++epoch;
@@ -150,10 +136,32 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     const int par = (int)(epoch & 1u);
     if (wave == 0) {
       if (lane < P) gran_store(mbox + (par * 8 + mk) * P + lane, epoch, v);
-      // lanes [0,32) read the even members, lanes [32,64) the odd ones (P = 32);
-      // for P = 16 four lane groups take members 0,1,2,3 mod 4
+      constexpr int MAXG = 8 / SL;  // granules per lane: members slot, slot+SL, ...
+      tile_gran_t g[MAXG];
+      uint64_t t0 = 0;
+      bool aborted = s_abort != 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < MAXG; ++j) {
+          const int kk = slot + j * SL;
+          g[j] = kk < K ? gran_load(mbox + (par * 8 + kk) * P + q) : ((tile_gran_t)epoch << 32);
+        }
+#pragma unroll
+        for (int j = 0; j < MAXG; ++j) ok &= (uint32_t)(g[j] >> 32) == epoch;
+        if (__all(ok) || aborted) break;
+        if (t0 == 0) t0 = wall_clock64();
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > 1000000000ull) {  // 10 s at 100 MHz: give up, loudly
+          aborted = true;
+          s_abort = 1;
+          atomicExch(S.overflow, 2);
+        }
+      }
       float tot = 0.0f;
-      for (int kk = slot; kk < K; kk += SL) tot += wait_gran(mbox + (par * 8 + kk) * P + q, epoch);
+#pragma unroll
+      for (int j = 0; j < MAXG; ++j)
+        if (slot + j * SL < K) tot += __uint_as_float((uint32_t)g[j]);
       if (SL == 4) tot += __shfl_xor(tot, 16);
       tot += __shfl_xor(tot, 32);
       if (lane < P) s_tot[par][q] = tot;
@@ -332,6 +340,11 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       return clock64();
     };
 
+    // ids/values of the NEXT visit's first block, fetched before this visit's barrier and
+    // cluster exchange so that the next gather can start as soon as the update is out
+    int pf_id = 0, pf_n = 0, pf_col = -1;
+    float pf_v = 0.0f;
+
     const char* __restrict__ rb = reinterpret_cast<const char*>(r);
     char* __restrict__ rbw = reinterpret_cast<char*>(r);
     const uint32_t qoff = (uint32_t)q << 2;
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     // [s, e) is this member's slice of column i, len the length of the whole column
     auto visit = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
                      const float xi, const float cn, const float sq, const bool live, float& dlt,
-                     const int mode) {
+                     const int mode, const int nxt_i, const int64_t nxt_s, const int64_t nxt_e) {
       const bool part = live && tile_active(xi);
       if (!__any(part)) return;
       constexpr int64_t CH = 64 * NW;  // nnz per workgroup chunk
@@ -399,13 +412,33 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       const uint64_t p0 = tick();
       float acc = 0.0f;
       int64_t c0 = s;
+      bool have_first = pf_col == i;  // first block already fetched by the previous visit
       for (; c0 + CH < e; c0 += CH) {
-        load_ids(c0);
+        if (have_first) {
+          idreg = pf_id; vreg = pf_v; nhere = pf_n;
+          have_first = false;
+        } else {
+          load_ids(c0);
+        }
         gather();
         if (mode == 0) acc += dot_block();
       }
-      load_ids(c0);  // last chunk: kept in registers for the update
+      if (have_first) {
+        idreg = pf_id; vreg = pf_v; nhere = pf_n;
+      } else {
+        load_ids(c0);  // last chunk: kept in registers for the update
+      }
       gather();
+      pf_col = -1;
+      if (nxt_i >= 0) {  // issue the next visit's first block now; it lands under the
+        const int64_t b0 = nxt_s + 64 * wave;  // barrier / exchange / update below
+        const int64_t left = nxt_e - b0;
+        pf_n = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+        const bool okn = lane < pf_n;
+        pf_id = okn ? ci[b0 + lane] - ubase : 0;
+        pf_v = okn ? (HAS_VAL ? cv[b0 + lane] : 1.0f) : 0.0f;
+        pf_col = nxt_i;
+      }
       const uint64_t p1 = tick();
 
       float d = 0.0f, nx = xi;
@@ -471,7 +504,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
         const int i = uni(ul[p]);
         const int64_t* sp = csplit + (int64_t)i * (K + 1);
         visit(i, uni(sp[mk]), uni(sp[mk + 1]), uni(sp[K]) - uni(sp[0]), x[(int64_t)i * P + q],
-              0.0f, 0.0f, !done_q, unused, 1);
+              0.0f, 0.0f, !done_q, unused, 1, -1, 0, 0);
       }
     }
 
@@ -486,30 +519,38 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       float dlt = 0.0f;
       const PermCtx pc = perm_make((uint32_t)nunion, perm_key(S.seed, (uint32_t)grp, (uint32_t)t));
       if (nunion > 0) {
-        // two-deep software pipeline on the visit scalars: the column id two visits
-        // ahead and the offsets / x row / norms one visit ahead are in flight while the
-        // current column is processed (values stay in VGPRs until they are consumed)
-        int i_n1 = ul[perm_index(pc, 0u)];
-        int i_n2 = nunion > 1 ? ul[perm_index(pc, 1u)] : 0;
-        const int64_t* sp0 = csplit + (int64_t)i_n1 * (K + 1);
-        int64_t s_n = sp0[mk], e_n = sp0[mk + 1], l_n = sp0[K] - sp0[0];
-        float xi_n = x[(int64_t)i_n1 * P + q], cn_n = A.cnorm[i_n1], sq_n = A.csq[i_n1];
+        // software pipeline on the visit scalars: column ids are read three visits ahead,
+        // slice offsets / x row / norms two visits ahead, so that at visit p the scalars of
+        // p and p+1 are already in registers (values stay in VGPRs until consumed)
+        struct Meta { int i; int64_t s; int n, len; float xi, cn, sq; };
+        auto load_meta = [&](const int iraw) -> Meta {
+          Meta m;
+          const int64_t* sp = csplit + (int64_t)iraw * (K + 1);
+          m.i = iraw;
+          m.s = sp[mk];
+          m.n = (int)(sp[mk + 1] - m.s);
+          m.len = (int)(sp[K] - sp[0]);
+          m.xi = x[(int64_t)iraw * P + q];
+          m.cn = A.cnorm[iraw];
+          m.sq = A.csq[iraw];
+          return m;
+        };
+        Meta mA = load_meta(ul[perm_index(pc, 0u)]);
+        Meta mB = mA;
+        if (nunion > 1) mB = load_meta(ul[perm_index(pc, 1u)]);
+        int i_c = nunion > 2 ? ul[perm_index(pc, 2u)] : 0;
         for (int p = 0; p < nunion; ++p) {
-          const int i = uni(i_n1);
-          const int64_t s = uni(s_n), e = uni(e_n), len = uni(l_n);
-          const float xi = xi_n, cn = uni(cn_n), sq = uni(sq_n);
-          if (p + 1 < nunion) {
-            i_n1 = i_n2;
-            const int64_t* spn = csplit + (int64_t)i_n1 * (K + 1);
-            s_n = spn[mk];
-            e_n = spn[mk + 1];
-            l_n = spn[K] - spn[0];
-            xi_n = x[(int64_t)i_n1 * P + q];
-            cn_n = A.cnorm[i_n1];
-            sq_n = A.csq[i_n1];
-            if (p + 2 < nunion) i_n2 = ul[perm_index(pc, (uint32_t)(p + 2))];
-          }
-          visit(i, s, e, len, xi, cn, sq, live, dlt, 0);
+          const int i = uni(mA.i);
+          const int64_t s = uni(mA.s), e = s + uni(mA.n);
+          const int64_t len = uni(mA.len);
+          const float xi = mA.xi, cn = uni(mA.cn), sq = uni(mA.sq);
+          mA = mB;  // visit p+1: loaded one visit ago
+          if (p + 2 < nunion) mB = load_meta(i_c);
+          if (p + 3 < nunion) i_c = ul[perm_index(pc, (uint32_t)(p + 3))];
+          const bool has_next = p + 1 < nunion;
+          const int64_t ns = has_next ? uni(mA.s) : 0;
+          visit(i, s, e, len, xi, cn, sq, live, dlt, 0, has_next ? uni(mA.i) : -1, ns,
+                has_next ? ns + uni(mA.n) : 0);
         }
       }
       if (live && dlt < S.opt_tol) {  // cd.c:135-138

@@ -64,9 +64,11 @@ def _default_device():
     return torch.device("cpu")
 
 
-def gather_model(W_local, group=None):
+def gather_model(W_local, group=None, dst=None):
     """All-gather column-disjoint pieces of W (scipy CSC, full n x n shape, only this
-    rank's columns populated) into the complete model on every rank."""
+    rank's columns populated) into the complete model -- on every rank, or (dst given)
+    assembled on rank ``dst`` only; the other ranks take part in the collectives and
+    return None."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -90,6 +92,8 @@ def gather_model(W_local, group=None):
     all_val = [torch.empty_like(val) for _ in range(world)]
     dist.all_gather(all_ind, ind, group=group)
     dist.all_gather(all_val, val, group=group)
+    if dst is not None and dist.get_rank(group) != dst:
+        return None
     # rank r's entries are the columns of its block in ascending column order, and blocks
     # ascend with the rank, so concatenation in rank order is the global CSC order --
     # provided every rank's populated columns form one contiguous block.

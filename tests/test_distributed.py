@@ -88,6 +88,10 @@ def _worker(rank, world, port, out_dir):
         part = sp.csc_matrix(W)[:, :n] if rank == 0 else sp.csc_matrix((n, n), dtype=np.float32)
         full = gather_model(part)
         assert abs(full - W).max() == 0
+        only0 = gather_model(part, dst=0)
+        assert (only0 is None) == (rank != 0)
+        if rank == 0:
+            assert abs(only0 - W).max() == 0
     finally:
         dist.destroy_process_group()
 
