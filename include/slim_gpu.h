@@ -153,6 +153,11 @@ int32_t SLIMGPU_MatrixColumnCost(const slimgpu_matrix_t *mat, int64_t *cost);
 slim_t *SLIMGPU_Learn(slimgpu_matrix_t *mat, int32_t *ioptions,
                       double *doptions, slim_t *imodel, int32_t *r_status);
 
+/* Py_SLIM_Predict on the GPU (one wavefront per user; lists and scores are bit-identical
+ * to the host scorer, ties included).  1 <= nrcmds <= 128.  Fails without a device. */
+int32_t SLIMGPU_Predict(int32_t nrcmds, slim_t *slimhandle, slim_t *trnhandle,
+                        int32_t *output, float *scores);
+
 /* Counters of the most recent solve on this thread. */
 typedef struct slimgpu_stats_t {
   int32_t ncols_solved;

@@ -52,4 +52,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
 
 int32_t device_count();
 
+// topn.hip: top-N lists of every row of `hist` through model W, on the GPU, bit-identical
+// to host_csr.cpp::top_n.  counts (optional): list length per user.
+int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcmds,
+                       int32_t* output, float* scores, int32_t* counts);
+
 }  // namespace slimamd

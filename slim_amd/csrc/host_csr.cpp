@@ -208,7 +208,7 @@ int32_t* head_tail_split(int32_t nrows, int32_t ncols, const ssize_t* rowptr,
 
 EvalResult evaluate(const slim_csr_t* model, const slim_csr_t* trn,
                     const slim_csr_t* tst, int32_t nrcmds, const int32_t* fmarker,
-                    int32_t fm_ncols) {
+                    int32_t fm_ncols, const int32_t* lists, const int32_t* counts) {
   EvalResult out;
   TopNScratch ws(std::max(model->ncols, model->nrows));
   std::vector<int32_t> rids(nrcmds);
@@ -221,9 +221,14 @@ EvalResult evaluate(const slim_csr_t* model, const slim_csr_t* trn,
     const ssize_t t0 = tst->rowptr[u], t1 = tst->rowptr[u + 1];
     if (t1 - t0 < 1) continue;
     const ssize_t h0 = trn->rowptr[u], h1 = trn->rowptr[u + 1];
-    const int32_t n = top_n(model, int32_t(h1 - h0), trn->rowind + h0,
-                            trn->rowval ? trn->rowval + h0 : nullptr, nrcmds,
-                            rids.data(), rsc.data(), ws);
+    int32_t n;
+    if (lists) {
+      n = counts[u];
+      std::copy(lists + (size_t)u * nrcmds, lists + (size_t)u * nrcmds + n, rids.begin());
+    } else {
+      n = top_n(model, int32_t(h1 - h0), trn->rowind + h0,
+                trn->rowval ? trn->rowval + h0 : nullptr, nrcmds, rids.data(), rsc.data(), ws);
+    }
     ++out.nvalid;
     int32_t ntrue[2] = {0, 0}, nhits[3] = {0, 0, 0};
     bool has_head = false, has_tail = false;

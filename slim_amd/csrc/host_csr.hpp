@@ -69,9 +69,12 @@ struct EvalResult {
   int32_t nvalid = 0, nvalid_head = 0, nvalid_tail = 0;
 };
 // pyapi.c:309-366: HR/ARHR of `model` for users with a non-empty test row.
+// lists/counts (optional): top-N ids [nusers][nrcmds] and list lengths computed elsewhere
+// (the GPU scorer); when null the host scorer is used.
 EvalResult evaluate(const slim_csr_t* model, const slim_csr_t* trn,
                     const slim_csr_t* tst, int32_t nrcmds, const int32_t* fmarker,
-                    int32_t fm_ncols);
+                    int32_t fm_ncols, const int32_t* lists = nullptr,
+                    const int32_t* counts = nullptr);
 
 // ---- files ------------------------------------------------------------------
 bool write_binrow(const slim_csr_t* m, const char* path);   // api.c:174-177

@@ -223,7 +223,14 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
         rc = status;
         break;
       }
-      const EvalResult ev = evaluate(model, trn, tst, nrcmds, fmarker, ncols);
+      // top-N of every user on the GPU (bit-identical to the host scorer), hits on the host
+      std::vector<int32_t> lists((size_t)trn->nrows * nrcmds, -1), lens((size_t)trn->nrows, 0);
+      std::vector<float> lsc((size_t)trn->nrows * nrcmds, 0.0f);
+      const bool on_gpu = nrcmds <= 128 && predict_device(model, trn, nrcmds, lists.data(),
+                                                          lsc.data(), lens.data()) == SLIM_OK;
+      const EvalResult ev = on_gpu ? evaluate(model, trn, tst, nrcmds, fmarker, ncols,
+                                              lists.data(), lens.data())
+                                   : evaluate(model, trn, tst, nrcmds, fmarker, ncols);
       std::printf("l1r: %.2le l2r: %.2le nnz: %7zd hr: %.4f hr_head: %.4f hr_tail: %.4f "
                   "arhr: %.4f time: %.2lf\n",
                   opt.l1r, opt.l2r, model->rowptr[model->nrows], ev.hr, ev.hr_head, ev.hr_tail,
@@ -268,11 +275,32 @@ int32_t Py_SLIM_GetTopN_1vsk(slim_t* model, int32_t nratings, int32_t* itemids, 
   return top_n_1vsk(W, nratings, itemids, ratings, nrcmds, rids, rscores, nnegs, negitems);
 }
 
+// Where Py_SLIM_Predict scores: SLIM_PREDICT=gpu|cpu|auto (default auto: the GPU scorer when
+// a device is present and nrcmds <= 128, else the host scorer; both give identical lists).
+static int predict_policy() {
+  const char* e = std::getenv("SLIM_PREDICT");
+  if (e && std::strcmp(e, "cpu") == 0) return 0;
+  if (e && std::strcmp(e, "gpu") == 0) return 2;
+  return 1;
+}
+
+int32_t SLIMGPU_Predict(int32_t nrcmds, slim_t* slimhandle, slim_t* trnhandle, int32_t* output,
+                        float* scores) {
+  set_error("");
+  return predict_device(as_csr(slimhandle), as_csr(trnhandle), nrcmds, output, scores, nullptr);
+}
+
 int32_t Py_SLIM_Predict(int32_t nrcmds, slim_t* slimhandle, slim_t* trnhandle, int32_t* output,
                         float* scores) {
   const slim_csr_t* W = as_csr(slimhandle);
   const slim_csr_t* trn = as_csr(trnhandle);
   if (!W || !trn || !W->rowptr || !trn->rowptr || nrcmds < 0) return SLIM_ERROR;
+  const int policy = predict_policy();
+  if (policy == 2 || (policy == 1 && nrcmds >= 1 && nrcmds <= 128 && trn->nrows > 0 &&
+                      device_count() > 0)) {
+    const int32_t rc = predict_device(W, trn, nrcmds, output, scores, nullptr);
+    if (rc == SLIM_OK || policy == 2) return rc;
+  }
   TopNScratch ws(W->ncols > W->nrows ? W->ncols : W->nrows);
   std::vector<int32_t> rids(nrcmds);
   std::vector<float> rsc(nrcmds);

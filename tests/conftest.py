@@ -16,6 +16,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU kernel that never returns cannot be interrupted by a signal: give every GPU test a
+    hard (thread-method) timeout so a hang costs minutes, not the whole box."""
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(300, method="thread"))
+
+
 def has_gpu():
     try:
         from slim_amd import _lib

@@ -379,3 +379,82 @@ def test_edge_cases():
     mz = DeviceMatrix.from_scipy(Z)
     assert mz.learn()[0].nnz == 0
     mz.close()
+
+
+# ---- top-N prediction on the GPU ---------------------------------------------
+def _predict_both(lib, hm, hr, nusers, n):
+    import os
+    out_g = np.full(nusers * n, -1, np.int32)
+    sc_g = np.zeros(nusers * n, np.float32)
+    assert lib.SLIMGPU_Predict(n, hm, hr, out_g, sc_g) == SLIM_OK
+    out_c = np.full(nusers * n, -1, np.int32)
+    sc_c = np.zeros(nusers * n, np.float32)
+    os.environ["SLIM_PREDICT"] = "cpu"
+    try:
+        assert lib.Py_SLIM_Predict(n, hm, hr, out_c, sc_c) == SLIM_OK
+    finally:
+        del os.environ["SLIM_PREDICT"]
+    return out_g.reshape(nusers, n), sc_g.reshape(nusers, n), out_c.reshape(nusers, n), \
+        sc_c.reshape(nusers, n)
+
+
+def _wrap(lib, M):
+    M = sp.csr_matrix(M)
+    h = C.c_void_p()
+    val = np.ascontiguousarray(M.data, np.float32)
+    assert lib.Py_csr_wrapper(M.shape[0], np.ascontiguousarray(M.indptr, np.intp),
+                              np.ascontiguousarray(M.indices, np.int32),
+                              val.ctypes.data_as(C.c_void_p), C.byref(h)) == SLIM_OK
+    return h
+
+
+@pytest.mark.parametrize("n", [10, 50, 1])
+def test_gpu_topn_is_bit_identical_to_host(ml100k, ml_dev, n):
+    """GetRecommendations for every user (predict.c:15-71 via pyapi.c:530-563): ids AND
+    float scores of the GPU scorer equal the host scorer's, ties included."""
+    lib = _lib.load()
+    R, T = ml100k
+    hm, _ = ml_dev.learn(seed=1, return_handle=True)
+    hr = _wrap(lib, R)
+    ids_g, sc_g, ids_c, sc_c = _predict_both(lib, hm, hr, R.shape[0], n)
+    assert np.array_equal(ids_g, ids_c)
+    assert np.array_equal(sc_g, sc_c)
+    # and both are what the oracle's GetRecommendations gives
+    W = model_to_scipy(lib, hm, free=False)
+    o_ids, o_sc = O.predict(W, R, n)
+    assert np.array_equal(ids_g, o_ids) and np.array_equal(sc_g, o_sc)
+    # Py_SLIM_Predict's default policy picks the GPU scorer when a device is present
+    out = np.full(R.shape[0] * n, -1, np.int32)
+    sc = np.zeros(R.shape[0] * n, np.float32)
+    assert lib.Py_SLIM_Predict(n, hm, hr, out, sc) == SLIM_OK
+    assert np.array_equal(out.reshape(-1, n), ids_c)
+    lib.Py_csr_free(hr)
+    h = C.c_void_p(hm)
+    lib.SLIM_FreeModel(C.byref(h))
+
+
+def test_gpu_topn_ratings_short_lists_and_ties(automotive):
+    lib = _lib.load()
+    R, T, users, items = automotive
+    m = DeviceMatrix.from_scipy(R)
+    hm, _ = m.learn(l1r=20.0, l2r=1.0, niters=100, return_handle=True)  # sparse model: short lists
+    hr = _wrap(lib, R)
+    ids_g, sc_g, ids_c, sc_c = _predict_both(lib, hm, hr, R.shape[0], 20)
+    assert np.array_equal(ids_g, ids_c) and np.array_equal(sc_g, sc_c)
+    assert (ids_c == -1).any()              # some users have fewer than 20 candidates
+    # a model with many exactly tied scores: W = all ones on a band
+    n = 300
+    Wt = sp.diags([np.ones(n - k, np.float32) for k in (1, 2, 3)], [1, 2, 3], format="csr")
+    from slim_amd.engine import _scipy_to_model_handle
+    ht = _scipy_to_model_handle(lib, Wt)
+    H = sp.random(200, n, density=0.03, format="csr", random_state=np.random.default_rng(3),
+                  dtype=np.float32)
+    H.data[:] = 1.0
+    hh = _wrap(lib, sp.csr_matrix((H.data, H.indices, H.indptr), shape=(200, n)))
+    ids_g, sc_g, ids_c, sc_c = _predict_both(lib, ht, hh, 200, 7)
+    assert np.array_equal(ids_g, ids_c) and np.array_equal(sc_g, sc_c)
+    for h in (hr, hh):
+        lib.Py_csr_free(h)
+    for h in (C.c_void_p(hm), ht):
+        lib.SLIM_FreeModel(C.byref(h))
+    m.close()
