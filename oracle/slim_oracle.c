@@ -215,7 +215,63 @@ typedef struct {
   int32_t aty;             /* ATY_* : estimate.c:412-421 vs Gram-column */
   int32_t fp32;            /* 0: reference arithmetic (fp64 x/yhat, 3-pass)
                               1: engine-style arithmetic (fp32 residual, fused) */
+  int32_t nnbrs;           /* > 0: FSLIM, api.c:43,55-56 */
+  int32_t simtype;         /* 0 cos, 1 jac, 2 dotp (slim.h:196-200) */
 } oracle_cfg_t;
+
+static void fkv_sortd_stable(fkv_t *a, int64_t n);
+
+/* neighbors.c:16-125 FindColumnNeighbors: candidates = items co-rated with iC,
+ * similarity accumulated in FLOAT over (users of iC ascending, row order)
+ * (neighbors.c:46-60), cos: / cnorm[k] (:82-83), jac: / (cnorm[k] + cnorm[iC] - key)
+ * (:107-109, norms not squared, as in the reference), dotp: as is; the nnbrs
+ * best are kept.  gk_dfkvkselect/gk_fkvsortd leave ties undefined upstream:
+ * here (similarity descending, item id ascending).  marker/cand: ncols scratch. */
+static int32_t find_neighbors(const oracle_cfg_t *cfg, int32_t nrows,
+                              const int64_t *rowptr, const int32_t *rowind,
+                              const float *rowval, const cview_t *A, int32_t iC,
+                              int32_t *marker, fkv_t *cand) {
+  (void)nrows;
+  if (A->colptr[iC] == A->colptr[iC + 1]) return 0; /* neighbors.c:31-32 */
+  int32_t ncand = 0;
+  for (int64_t ii = A->colptr[iC]; ii < A->colptr[iC + 1]; ii++) {
+    const int32_t u = A->colind[ii];
+    const float cval = A->colval ? A->colval[ii] : 1.0f;
+    for (int64_t j = rowptr[u]; j < rowptr[u + 1]; j++) {
+      const int32_t k = rowind[j];
+      if (k == iC) continue;
+      if (marker[k] == -1) {
+        cand[ncand].val = k;
+        cand[ncand].key = 0;
+        marker[k] = ncand++;
+      }
+      if (rowval)
+        cand[marker[k]].key += rowval[j] * cval;
+      else
+        cand[marker[k]].key += cval;
+    }
+  }
+  for (int32_t i = 0; i < ncand; i++) {
+    const int64_t k = cand[i].val;
+    if (cfg->simtype == 0)
+      cand[i].key = cand[i].key / A->cnorms[k];
+    else if (cfg->simtype == 1)
+      cand[i].key = cand[i].key / (A->cnorms[k] + A->cnorms[iC] - cand[i].key);
+    marker[k] = -1;
+  }
+  /* top nnbrs: similarity descending, then item id ascending */
+  for (int32_t a = 1; a < ncand; a++) { /* order by id first (insertion sort is fine: */
+    fkv_t t = cand[a];                   /* candidates arrive nearly sorted per row)   */
+    int32_t b = a;
+    while (b > 0 && cand[b - 1].val > t.val) {
+      cand[b] = cand[b - 1];
+      b--;
+    }
+    cand[b] = t;
+  }
+  fkv_sortd_stable(cand, ncand);
+  return ncand < cfg->nnbrs ? ncand : cfg->nnbrs;
+}
 
 /* per-column counters (SURVEY 8(d) algorithmic-bytes terms) */
 typedef struct {
@@ -396,6 +452,9 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
     float *rf = cfg->fp32 ? (float *)calloc((size_t)nrows, sizeof(float)) : NULL;
     fkv_t *act = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)ncols);
     fkv_t *tmp = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)ncols);
+    int32_t *nmark = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
+    fkv_t *ncand = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)ncols);
+    for (int32_t i = 0; i < ncols; i++) nmark[i] = -1;
     int tid = 0;
 #ifdef _OPENMP
     tid = omp_get_thread_num();
@@ -443,12 +502,36 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
       /* estimate.c:433-444 active set: strict '>' against l1r, diag excluded,
        * key stored as float, x flagged -0.1 for the warm-start test          */
       int32_t na = 0;
-      for (int32_t i = 0; i < ncols; i++) {
-        if (ATy[i] > cfg->l1r && i != iC) {
-          act[na].val = i;
-          act[na].key = (float)ATy[i];
-          na++;
-          x[i] = -0.1;
+      if (cfg->nnbrs > 0) {
+        /* estimate.c:424-431 FSLIM: the active set is the neighbour list, with no
+         * l1 screen and without the -0.1 flags (warm start is a no-op there)    */
+        na = find_neighbors(cfg, nrows, rowptr, rowind, rowval, &A, iC, nmark, ncand);
+        if (cfg->order == ORDER_PERM) {
+          /* the engine keeps every active list in ascending id order and permutes
+           * positions; the reference keeps similarity order and shuffles it.  Either
+           * only seeds the visiting order. */
+          for (int32_t a = 1; a < na; a++) {
+            fkv_t t = ncand[a];
+            int32_t b = a;
+            while (b > 0 && ncand[b - 1].val > t.val) {
+              ncand[b] = ncand[b - 1];
+              b--;
+            }
+            ncand[b] = t;
+          }
+        }
+        for (int32_t i = 0; i < na; i++) {
+          act[i].val = ncand[i].val;
+          act[i].key = (float)ATy[ncand[i].val];
+        }
+      } else {
+        for (int32_t i = 0; i < ncols; i++) {
+          if (ATy[i] > cfg->l1r && i != iC) {
+            act[na].val = i;
+            act[na].key = (float)ATy[i];
+            na++;
+            x[i] = -0.1;
+          }
         }
       }
 
@@ -552,6 +635,8 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
     free(rf);
     free(act);
     free(tmp);
+    free(nmark);
+    free(ncand);
   }
 
   /* estimate.c:570-589 SaveModel, column view */

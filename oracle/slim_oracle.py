@@ -22,7 +22,8 @@ class Cfg(C.Structure):
     _fields_ = [("l1r", C.c_double), ("l2r", C.c_double), ("optTol", C.c_double),
                 ("maxniters", C.c_int32), ("nthreads", C.c_int32),
                 ("order", C.c_int32), ("seed", C.c_uint32),
-                ("aty", C.c_int32), ("fp32", C.c_int32)]
+                ("aty", C.c_int32), ("fp32", C.c_int32),
+                ("nnbrs", C.c_int32), ("simtype", C.c_int32)]
 
 
 class ColStat(C.Structure):
@@ -77,14 +78,15 @@ def _csr_arrays(R, binary=False):
 
 def learn_cd(R, l1r=1.0, l2r=1.0, optTol=1e-7, maxniters=10000, nthreads=1,
              order=ORDER_GLIBC, seed=1, aty=ATY_FULLSCAN, fp32=False,
-             imodel=None, cols=None, binary=False, srand=1, return_stats=False):
+             imodel=None, cols=None, binary=False, srand=1, return_stats=False,
+             nnbrs=0, simtype=0):
     """Restated SLIM_Learn(algo=cd).  R: scipy CSR (ids used as given; model
     dimension = max id + 1, setup.c:117).  imodel: scipy sparse W of a previous
     solve (warm start through its column view).  Returns W as scipy CSC
     (column iC = regressors of item iC) [+ stats, error, objval]."""
     L = lib()
     nrows, ptr, ind, val = _csr_arrays(R, binary)
-    cfg = Cfg(l1r, l2r, optTol, maxniters, nthreads, order, seed, aty, int(fp32))
+    cfg = Cfg(l1r, l2r, optTol, maxniters, nthreads, order, seed, aty, int(fp32), nnbrs, simtype)
     if order == ORDER_GLIBC and srand is not None:
         L.oracle_srand(C.c_uint32(srand))
     ic_ptr = ic_ind = ic_val = None
@@ -146,7 +148,7 @@ def learn_cd_tile(R, tileP=32, order=None, l1r=1.0, l2r=1.0, optTol=1e-7, maxnit
     if order is None:
         order = tile_work_order(R)
     order = np.ascontiguousarray(order, dtype=np.int32)
-    cfg = Cfg(l1r, l2r, optTol, maxniters, nthreads, ORDER_PERM, seed, ATY_GRAM, 0)
+    cfg = Cfg(l1r, l2r, optTol, maxniters, nthreads, ORDER_PERM, seed, ATY_GRAM, 0, 0, 0)
     ncols = int(ind.max()) + 1 if ind.size else 0
     stats = np.zeros(ncols, dtype=COLSTAT_DTYPE)
     wptr, wind, wval = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_float)()

@@ -53,6 +53,8 @@ struct SolveArgs {
   float l1, l2, opt_tol;
   int32_t maxniters;
   uint32_t seed;
+  int32_t nnbrs;    // > 0: FSLIM, the active set is the nnbrs most similar columns
+  int32_t simtype;  // 0 cos, 1 jac, 2 dotp (slim.h:196-200)
   // work list (item ids, most expensive first) and the queue head
   const int32_t* order;
   int32_t nwork;
@@ -219,8 +221,66 @@ __global__ __launch_bounds__(64) void cd_wave_kernel(const DevMatrix A, const So
     }
     wave_sync<USE_LDS>();
 
-    // -- 3: active list by ballot compaction (in place: slot <= item id)
+    // -- 3: active list
     int na = 0;
+    if (S.nnbrs > 0) {
+      // FSLIM (estimate.c:424-431, neighbors.c:16-125): the nnbrs columns most similar to
+      // iC among those sharing a user with it; no l1 screen.  The co-rating dot products
+      // are the Gram column just computed.  Ties (undefined upstream): lower item id first.
+      const float ninf = -__builtin_huge_valf();
+      const float cn_c = A.cnorm[iC];
+      for (int i = lane; i < ncols; i += 64) {
+        const float a = aty[i];
+        float sim = ninf;
+        if (a != 0.0f && i != iC) {
+          const float cn_i = A.cnorm[i];
+          sim = S.simtype == 0 ? a / cn_i : (S.simtype == 1 ? a / ((cn_i + cn_c) - a) : a);
+        }
+        aty[i] = sim;
+      }
+      wave_sync<USE_LDS>();
+      int* sel = reinterpret_cast<int*>(x);  // selected ids, in similarity order
+      for (int round = 0; round < S.nnbrs; ++round) {
+        float bs = ninf;
+        int bi = 0x7fffffff;
+        for (int i = lane; i < ncols; i += 64) {  // ascending i per lane: first max wins
+          const float sv = aty[i];
+          if (sv > bs) {
+            bs = sv;
+            bi = i;
+          }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const float os = __shfl_xor(bs, off);
+          const int oi = __shfl_xor(bi, off);
+          const bool take = os > bs || (os == bs && oi < bi);
+          bs = take ? os : bs;
+          bi = take ? oi : bi;
+        }
+        bs = uni(bs);
+        bi = uni(bi);
+        if (!(bs > ninf)) break;  // fewer candidates than nnbrs (wave-uniform)
+        if (lane == 0) {
+          sel[na] = bi;
+          aty[bi] = ninf;
+        }
+        ++na;
+        wave_sync<USE_LDS>();
+      }
+      // the active list is kept in ascending id order (output order, warm-start search)
+      int myid = 0, rank = 0;
+      for (int b = 0; b < na; b += 64) {  // na <= nnbrs entries, 64 per pass
+        const int e = b + lane;
+        myid = e < na ? sel[e] : 0;
+        rank = 0;
+        for (int o = 0; o < na; ++o) rank += (sel[o] < myid) ? 1 : 0;
+        wave_sync<USE_LDS>();
+        if (e < na) ids[rank] = myid;  // ids aliases aty: similarities are dead by now
+      }
+      wave_sync<USE_LDS>();
+      for (int e = lane; e < na; e += 64) x[e] = 0.0f;
+    } else
     for (int base = 0; base < ncols; base += 64) {
       const int i = base + lane;
       const float a = i < ncols ? aty[i] : 0.0f;
@@ -238,7 +298,7 @@ __global__ __launch_bounds__(64) void cd_wave_kernel(const DevMatrix A, const So
 
     // -- 4: warm start.  imodel column iC is ascending; binary-search each of
     //    its ids in the active list, then fold the non-zero x into r
-    if (S.icolptr != nullptr && iC < S.incols) {
+    if (S.nnbrs == 0 && S.icolptr != nullptr && iC < S.incols) {
       const int64_t ws = uni(S.icolptr[iC]), we = uni(S.icolptr[iC + 1]);
       for (int64_t e = ws + lane; e < we; e += 64) {
         const int k = S.icolind[e];

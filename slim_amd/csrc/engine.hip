@@ -572,6 +572,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int kernel = opt.kernel;
     if (kernel == SLIMGPU_KERNEL_AUTO)
       kernel = lds_need <= 64 * 1024 ? SLIMGPU_KERNEL_WAVE_LDS : SLIMGPU_KERNEL_TILE;
+    // FSLIM (nnbrs > 0) selects its active set per item: one wavefront per item
+    if (opt.nnbrs > 0 && (kernel == SLIMGPU_KERNEL_TILE || kernel == SLIMGPU_KERNEL_TILE16))
+      kernel = SLIMGPU_KERNEL_WAVE_HBM;
     if (kernel == SLIMGPU_KERNEL_WAVE_LDS && lds_need > 160 * 1024) {
       set_error("SLIMGPU_Learn: work vectors do not fit the 160 KiB LDS of a CU");
       return fail(SLIM_ERROR_INPUT);
@@ -749,6 +752,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.opt_tol = (float)opt.optTol;
       S.maxniters = opt.maxniters;
       S.seed = opt.seed;
+      S.nnbrs = opt.nnbrs;
+      S.simtype = opt.simtype;
       S.order = d_order;
       S.nwork = npend;
       S.queue = d_misc;

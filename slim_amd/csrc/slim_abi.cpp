@@ -32,8 +32,8 @@ slim_csr_t* learn_from_host(int32_t nrows, const ssize_t* rowptr, const int32_t*
     *status = SLIM_ERROR_INPUT;
     return nullptr;
   }
-  if (opt.nnbrs > 0) {
-    set_error("fSLIM (nnbrs > 0) is not implemented by this engine yet");
+  if (opt.simtype < SLIM_SIMTYPE_COS || opt.simtype > SLIM_SIMTYPE_DOTP) {
+    set_error("unknown similarity type (neighbors.c:121-123)");
     *status = SLIM_ERROR_INPUT;
     return nullptr;
   }
@@ -179,8 +179,8 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
   LearnOptions base = decode_options(ioptions, doptions);
   const int32_t nrcmds =
       (!ioptions || ioptions[SLIM_OPTION_NRCMDS] == -1) ? 10 : ioptions[SLIM_OPTION_NRCMDS];
-  if (base.algo != SLIM_ALGO_CD || base.nnbrs > 0) {
-    set_error("Py_SLIM_Mselect: only algo=cd, nnbrs=0 is implemented by this engine");
+  if (base.algo != SLIM_ALGO_CD) {
+    set_error("Py_SLIM_Mselect: only algo=cd is implemented by this engine");
     return SLIM_ERROR_INPUT;
   }
 
@@ -388,8 +388,8 @@ slim_t* SLIMGPU_Learn(slimgpu_matrix_t* mat, int32_t* ioptions, double* doptions
   int32_t status = SLIM_ERROR;
   LearnOptions opt = decode_options(ioptions, doptions);
   slim_csr_t* model = nullptr;
-  if (opt.algo != SLIM_ALGO_CD || opt.nnbrs > 0) {
-    set_error("SLIMGPU_Learn: only algo=cd, nnbrs=0 is implemented");
+  if (opt.algo != SLIM_ALGO_CD) {
+    set_error("SLIMGPU_Learn: only algo=cd is implemented");
     status = SLIM_ERROR_INPUT;
   } else {
     model = learn_cd(mat, opt, as_csr(imodel), &status);

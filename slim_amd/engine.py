@@ -17,13 +17,16 @@ KERNEL_AUTO, KERNEL_WAVE_LDS, KERNEL_WAVE_HBM, KERNEL_TILE, KERNEL_TILE16 = 0, 1
 
 
 def make_options(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=1, col_begin=None,
-                 col_end=None, kernel=KERNEL_AUTO, device=None, dbglvl=0, cluster=None):
+                 col_end=None, kernel=KERNEL_AUTO, device=None, dbglvl=0, cluster=None, nnbrs=0,
+                 simtype=0):
     iopt = np.full(SLIM_NOPTIONS, -1, dtype=np.int32)
     dopt = np.full(SLIM_NOPTIONS, -1.0, dtype=np.float64)
     iopt[Opt.DBGLVL] = dbglvl
     iopt[Opt.MAXNITERS] = niters
     iopt[Opt.GPU_SEED] = seed
     iopt[Opt.GPU_KERNEL] = kernel
+    iopt[Opt.NNBRS] = nnbrs
+    iopt[Opt.SIMTYPE] = simtype
     if col_begin is not None:
         iopt[Opt.GPU_COLBEGIN] = col_begin
     if col_end is not None:

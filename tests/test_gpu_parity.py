@@ -458,3 +458,48 @@ def test_gpu_topn_ratings_short_lists_and_ties(automotive):
     for h in (C.c_void_p(hm), ht):
         lib.SLIM_FreeModel(C.byref(h))
     m.close()
+
+
+# ---- fSLIM (nnbrs > 0) -----------------------------------------------------------
+@pytest.mark.parametrize("simtype,name", [(0, "cos"), (1, "jac"), (2, "dotp")])
+def test_fslim_matches_oracle(automotive, simtype, name):
+    """FSLIM (estimate.c:424-431 + neighbors.c:16-125): per item only the nnbrs most similar
+    co-rated columns are regressors.  Same neighbour lists (tie rule: lower id) and, walking the
+    same order, the same W as the oracle."""
+    R, T, users, items = automotive
+    m = DeviceMatrix.from_scipy(R)
+    W, st = m.learn(l1r=1.0, l2r=1.0, niters=100, seed=3, nnbrs=10, simtype=simtype)
+    cs = m.column_stats()
+    Wo, so, err, obj = O.learn_cd(R, maxniters=100, order=O.ORDER_PERM, seed=3, aty=O.ATY_GRAM,
+                                  nthreads=8, nnbrs=10, simtype=simtype, return_stats=True)
+    assert cs.nacols.max() == 10 and np.array_equal(cs.nacols, so["nacols"])
+    assert maxdiff(W, Wo) <= 2e-5 and pattern_diff(W, Wo) <= 4
+    assert abs(st["objval"] - obj) <= 1e-4 * obj
+    assert np.diff(W.indptr).max() <= 10          # at most nnbrs regressors per item
+    # through the Python API, as the reference's notebook does (UserGuide.ipynb:300-328)
+    from conftest import GOLDEN
+    from slim_amd.io import read_ijv
+    trn = read_ijv(GOLDEN + "/AutomotiveTrain.ijv")
+    model = SLIM()
+    model.train({"algo": "cd", "nthreads": 1, "l1r": 1.0, "l2r": 1.0, "optTol": 1e-7,
+                 "niters": 100, "nnbrs": 10, "simtype": name, "gpu_seed": 3}, SLIMatrix(trn))
+    assert maxdiff(model.to_csr(), W) == 0.0
+    m.close()
+
+
+def test_fslim_more_neighbours_than_candidates(ml100k, ml_dev):
+    R, _ = ml100k
+    W, st = ml_dev.learn(seed=1, nnbrs=50, simtype=0)
+    Wo, so, _, _ = O.learn_cd(R, order=O.ORDER_PERM, seed=1, aty=O.ATY_GRAM, nthreads=8, nnbrs=50,
+                              simtype=0, return_stats=True)
+    cs = ml_dev.column_stats()
+    assert np.array_equal(cs.nacols, so["nacols"]) and cs.nacols.max() == 50
+    assert maxdiff(W, Wo) <= 2e-5
+    big, _ = ml_dev.learn(seed=1, nnbrs=5000, simtype=2, l1r=0.5)   # nnbrs > #candidates
+    big_o = O.learn_cd(R, order=O.ORDER_PERM, seed=1, aty=O.ATY_GRAM, nthreads=8, nnbrs=5000,
+                       simtype=2, l1r=0.5)
+    assert maxdiff(big, big_o) <= 2e-5
+    W_hbm, _ = ml_dev.learn(seed=1, nnbrs=50, simtype=0, kernel=KERNEL_WAVE_HBM)
+    assert maxdiff(W_hbm, W) == 0.0
+    W_tile, st_t = ml_dev.learn(seed=1, nnbrs=50, simtype=0, kernel=KERNEL_TILE)  # rerouted
+    assert st_t["kernel"] == KERNEL_WAVE_HBM and maxdiff(W_tile, W) == 0.0
