@@ -61,7 +61,7 @@
 
 namespace slimamd {
 
-constexpr int kTileNW = 16;  // wavefronts per workgroup
+constexpr int kTileNW = 16;  // wavefronts per workgroup (default geometry)
 constexpr float kInactive = -__builtin_huge_valf();
 __device__ __forceinline__ bool tile_active(float xv) { return xv > -3.0e38f; }
 
@@ -80,9 +80,13 @@ __device__ __forceinline__ tile_gran_t gran_load(const tile_gran_t* p) {
 
 // PROFILE adds s_memtime stamps around the phases of a visit (SLIM_GPU_TRACE=2); the
 // waits it needs perturb the schedule a little, so it is a separate instantiation.
-template <int P, bool HAS_VAL, bool PROFILE>
-__global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
-  constexpr int NW = kTileNW;
+// NW = wavefronts per workgroup: 16 (one workgroup per CU) or 8 (two per CU, whose phases
+// -- gather / barrier / cluster exchange / write-back -- then overlap).
+// (16 wavefronts per CU either way: the second launch bound, 4 waves per SIMD, caps the
+// kernel at 128 VGPRs)
+template <int P, bool HAS_VAL, bool PROFILE, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
+  constexpr int NT = 64 * NW;  // threads per workgroup
   constexpr int SL = 64 / P;       // users per wavefront step (lane groups)
   constexpr int STEPS = 64 / SL;   // steps per 64-nnz block (== P)
   constexpr int PPW = P / NW;      // problems served per wavefront in the per-problem phases
@@ -209,12 +213,12 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
       float4* x4 = reinterpret_cast<float4*>(x);
       const int64_t nr4 = (int64_t)(uend - ubase) * (P / 4), nx4 = (int64_t)ncols * (P / 4);
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int64_t k = tid; k < nr4; k += 1024) r4[k] = z;
-      for (int64_t k = tid; k < nx4; k += 1024) x4[k] = z;
+      for (int64_t k = tid; k < nr4; k += NT) r4[k] = z;
+      for (int64_t k = tid; k < nx4; k += NT) x4[k] = z;
       if (K > 1) {  // each member clears its share of the cluster's aTy accumulator
         float4* a4 = reinterpret_cast<float4*>(aty_sh);
         const int64_t lo = nx4 * mk / K, hi = nx4 * (mk + 1) / K;
-        for (int64_t k = lo + tid; k < hi; k += 1024) a4[k] = z;
+        for (int64_t k = lo + tid; k < hi; k += NT) a4[k] = z;
       }
     }
     cluster_barrier();
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(1024) void cd_tile_kernel(const DevMatrix A, const 
     // -- active sets (estimate.c:433-444): x = 0 for active, -inf for inactive
     {
       const int64_t n = (int64_t)ncols * P;
-      for (int64_t idx = tid; idx < n; idx += 1024) {
+      for (int64_t idx = tid; idx < n; idx += NT) {
         const int i = (int)(idx >> LOGP), qq = (int)(idx & (P - 1));
         const int it = s_item[qq];
         const bool act = it >= 0 && i != it && aty[idx] > l1;

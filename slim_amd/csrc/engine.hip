@@ -597,14 +597,21 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     const char* trace_env = std::getenv("SLIM_GPU_TRACE");
     const int trace_level = trace_env ? std::atoi(trace_env) : 0;
     KernelFn fn = pick_kernel(use_lds, !m->binary);
+    // tile workgroup geometry: 16 wavefronts (1 workgroup per CU) or 8 (2 per CU, phases of
+    // the two overlap).  SLIM_GPU_TILE_NW overrides the default.
+    int tileNW = 8;
+    if (const char* e = std::getenv("SLIM_GPU_TILE_NW")) tileNW = std::atoi(e) == 16 ? 16 : 8;
     if (use_tile) {
       const bool prof = trace_level >= 2;
+      const bool val = !m->binary;
+#define SLIM_TILE_PICK(PP, NWW)                                                              \
+  (val ? (prof ? cd_tile_kernel<PP, true, true, NWW> : cd_tile_kernel<PP, true, false, NWW>)  \
+       : (prof ? cd_tile_kernel<PP, false, true, NWW> : cd_tile_kernel<PP, false, false, NWW>))
       if (tileP == 32)
-        fn = m->binary ? (prof ? cd_tile_kernel<32, false, true> : cd_tile_kernel<32, false, false>)
-                       : (prof ? cd_tile_kernel<32, true, true> : cd_tile_kernel<32, true, false>);
+        fn = tileNW == 16 ? SLIM_TILE_PICK(32, 16) : SLIM_TILE_PICK(32, 8);
       else
-        fn = m->binary ? (prof ? cd_tile_kernel<16, false, true> : cd_tile_kernel<16, false, false>)
-                       : (prof ? cd_tile_kernel<16, true, true> : cd_tile_kernel<16, true, false>);
+        fn = tileNW == 16 ? SLIM_TILE_PICK(16, 16) : SLIM_TILE_PICK(16, 8);
+#undef SLIM_TILE_PICK
     }
     int waves_per_cu;
     if (use_lds) {
@@ -620,6 +627,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int nwaves = std::max(1, std::min(nwork, m->num_cus * waves_per_cu));
     size_t tile_r = 0, tile_x = 0, tile_u = 0;
     int clusterK = 1, cluster_lg = 0, nclusters = 0;
+    const int wg_slots = m->num_cus * (16 / tileNW);  // co-resident tile workgroups
     if (use_tile) {
       const int ngroups_all = (nwork + tileP - 1) / tileP;
       // cluster size: share a tile among K workgroups when there are too few tiles to keep
@@ -630,16 +638,16 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         // the heaviest tile runs ~7x the median (popular items need more sweeps): a
         // cluster should see >= ~8 tiles so the others fill in behind it; with fewer
         // tiles per cluster, larger clusters shorten that critical path instead
-        while (clusterK < 8 && (int64_t)ngroups_all * clusterK < 8 * (int64_t)m->num_cus)
+        while (clusterK < 8 && (int64_t)ngroups_all * clusterK < 8 * (int64_t)wg_slots)
           clusterK *= 2;
       }
-      while (clusterK > 1 && m->num_cus / clusterK < 1) clusterK /= 2;
+      while (clusterK > 1 && wg_slots / clusterK < 1) clusterK /= 2;
       for (cluster_lg = 0; (1 << cluster_lg) < clusterK; ++cluster_lg) {}
       ensure_cluster_split(m, cluster_lg);
       tile_r = (size_t)round_up(m->max_range_rows[cluster_lg], 64) * tileP;
       tile_x = (size_t)ncols_pad * tileP;
       tile_u = (size_t)ncols_pad;
-      nclusters = std::max(1, std::min(ngroups_all, m->num_cus / clusterK));
+      nclusters = std::max(1, std::min(ngroups_all, wg_slots / clusterK));
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
       const size_t per_cl = ((tile_r + tile_x) * sizeof(float) + tile_u * sizeof(int32_t)) * clusterK +
@@ -804,7 +812,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
           use_tile ? std::max(1, std::min((npend + tileP - 1) / tileP, nclusters)) * clusterK
                    : std::max(1, std::min(npend, nwaves));
       HIP_TRY(hipEventRecord(ev0, stream));
-      hipLaunchKernelGGL(fn, dim3(launch_waves), dim3(use_tile ? 64 * kTileNW : 64),
+      hipLaunchKernelGGL(fn, dim3(launch_waves), dim3(use_tile ? 64 * tileNW : 64),
                          use_lds ? lds_need : 0, stream, A, S);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(ev1, stream));
