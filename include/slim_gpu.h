@@ -102,7 +102,7 @@ enum {
   SLIM_OPTION_GPU_DEVICE = 14,   /* HIP device ordinal [current device]        */
   SLIM_OPTION_GPU_KERNEL = 15,   /* slimgpu_kernel_et [SLIMGPU_KERNEL_AUTO]    */
   SLIM_OPTION_GPU_CLUSTER = 16   /* tile kernels: workgroups sharing one tile,
-                                    1/2/4/8 [auto: by tiles per CU]            */
+                                    1/2/4/8/16 [auto: by tiles per cluster]            */
 };
 
 typedef enum {

@@ -43,7 +43,7 @@
 //
 // Clusters.  A tile's critical path is (sweeps of its slowest problem) x (time of
 // one sweep on one CU); the most popular items need ~4x the median sweeps, so with
-// few tiles per CU a launch waits for one workgroup.  K = 1, 2, 4 or 8 workgroups
+// few tiles per CU a launch waits for one workgroup.  K = 1, 2, 4, 8 or 16 workgroups
 // (a cluster) can therefore share a tile: the USERS are split into K ranges of equal
 // nnz, member k keeps only its range of r and walks only its slice of every column
 // (csplit[i][k] .. csplit[i][k+1], precomputed), and the P partial dots are summed
@@ -62,6 +62,7 @@
 namespace slimamd {
 
 constexpr int kTileNW = 16;  // wavefronts per workgroup (default geometry)
+constexpr int kTileKMax = 16;  // largest cluster (workgroups sharing one tile)
 constexpr float kInactive = -__builtin_huge_valf();
 __device__ __forceinline__ bool tile_active(float xv) { return xv > -3.0e38f; }
 
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
   const int K = S.cluster;
   const int cid = (int)blockIdx.x / K, mk = (int)blockIdx.x % K;
   const int ubase = S.ubounds[mk], uend = S.ubounds[mk + 1];
-  tile_gran_t* const mbox = S.mailbox + (int64_t)cid * (2 * 8 * P + 8);
+  tile_gran_t* const mbox = S.mailbox + (int64_t)cid * (2 * kTileKMax * P + 8);
   float* aty_sh = S.atyshared ? S.atyshared + (int64_t)cid * S.x_stride : nullptr;  // cluster aTy
   uint32_t epoch = 0;
   if (tid == 0) s_abort = 0;
@@ -139,8 +140,8 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
     if (epoch == 0) epoch = 1;
     const int par = (int)(epoch & 1u);
     if (wave == 0) {
-      if (lane < P) gran_store(mbox + (par * 8 + mk) * P + lane, epoch, v);
-      constexpr int MAXG = 8 / SL;  // granules per lane: members slot, slot+SL, ...
+      if (lane < P) gran_store(mbox + (par * kTileKMax + mk) * P + lane, epoch, v);
+      constexpr int MAXG = kTileKMax / SL;  // granules per lane: members slot, slot+SL, ...
       tile_gran_t g[MAXG];
       uint64_t t0 = 0;
       bool aborted = s_abort != 0;
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
 #pragma unroll
         for (int j = 0; j < MAXG; ++j) {
           const int kk = slot + j * SL;
-          g[j] = kk < K ? gran_load(mbox + (par * 8 + kk) * P + q) : ((tile_gran_t)epoch << 32);
+          g[j] = kk < K ? gran_load(mbox + (par * kTileKMax + kk) * P + q)
+                        : ((tile_gran_t)epoch << 32);
         }
 #pragma unroll
         for (int j = 0; j < MAXG; ++j) ok &= (uint32_t)(g[j] >> 32) == epoch;

@@ -45,9 +45,9 @@ struct slimgpu_matrix {
   std::vector<int64_t> h_cost;  // scheduling proxy per column (Gram work G)
   std::vector<int64_t> h_rowptr;  // host copy, fetched on first clustered solve
   // column slice boundaries for tile clusters of size K (index log2 K), built on demand
-  int32_t* d_ubounds[4] = {nullptr, nullptr, nullptr, nullptr};
-  int64_t* d_csplit[4] = {nullptr, nullptr, nullptr, nullptr};
-  int32_t max_range_rows[4] = {0, 0, 0, 0};
+  int32_t* d_ubounds[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t* d_csplit[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int32_t max_range_rows[5] = {0, 0, 0, 0, 0};
   double setup_ms = 0;
   int num_cus = 256;
   // workspace reused by successive solves
@@ -342,7 +342,7 @@ void destroy(slimgpu_matrix* m) {
   (void)hipFree(m->d_colval);
   (void)hipFree(m->d_cnorm);
   (void)hipFree(m->d_csq);
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < 5; ++k) {
     (void)hipFree(m->d_ubounds[k]);
     (void)hipFree(m->d_csplit[k]);
   }
@@ -599,7 +599,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     KernelFn fn = pick_kernel(use_lds, !m->binary);
     // tile workgroup geometry: 16 wavefronts (1 workgroup per CU) or 8 (2 per CU, phases of
     // the two overlap).  SLIM_GPU_TILE_NW overrides the default.
-    int tileNW = 8;
+    // Measured on C4 (profiles/r01): with few tiles per cluster the launch is bound by the
+    // slowest tile and one big workgroup per CU finishes it sooner (134 vs 109-116 col/s at
+    // 256 tiles); with many tiles throughput matters and two small workgroups win (150 vs
+    // ~141 col/s at 512 tiles).
+    int tileNW = (nwork + tileP - 1) / tileP >= 2 * m->num_cus ? 8 : 16;
     if (const char* e = std::getenv("SLIM_GPU_TILE_NW")) tileNW = std::atoi(e) == 16 ? 16 : 8;
     if (use_tile) {
       const bool prof = trace_level >= 2;
@@ -632,13 +636,18 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       const int ngroups_all = (nwork + tileP - 1) / tileP;
       // cluster size: share a tile among K workgroups when there are too few tiles to keep
       // every CU busy behind the slowest one (auto), or as requested
-      if (opt.cluster == 1 || opt.cluster == 2 || opt.cluster == 4 || opt.cluster == 8) {
+      if (opt.cluster == 1 || opt.cluster == 2 || opt.cluster == 4 || opt.cluster == 8 ||
+          opt.cluster == 16) {
         clusterK = opt.cluster;
       } else {
         // the heaviest tile runs ~7x the median (popular items need more sweeps): a
         // cluster should see >= ~8 tiles so the others fill in behind it; with fewer
         // tiles per cluster, larger clusters shorten that critical path instead
-        while (clusterK < 8 && (int64_t)ngroups_all * clusterK < 8 * (int64_t)wg_slots)
+        // ... but a member's slice of a column should stay long enough (>= ~512 nnz on
+        // average) for the gather to amortise the per-visit exchange
+        int cap = 1;
+        while (cap < kTileKMax && (m->nnz / std::max(ncols, 1)) / (2 * cap) >= 512) cap *= 2;
+        while (clusterK < cap && (int64_t)ngroups_all * clusterK < 8 * (int64_t)wg_slots)
           clusterK *= 2;
       }
       while (clusterK > 1 && wg_slots / clusterK < 1) clusterK /= 2;
@@ -673,7 +682,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int32_t* d_ulist = nullptr;
     unsigned long long* d_mailbox = nullptr;
     float* d_atysh = nullptr;
-    const size_t mailbox_words = (size_t)std::max(nclusters, 1) * (2 * 8 * (size_t)tileP + 8);
+    const size_t mailbox_words =
+        (size_t)std::max(nclusters, 1) * (2 * (size_t)kTileKMax * (size_t)tileP + 8);
     if (use_tile) {
       d_slab = ws_get<float>(m->ws_slab, tile_r * (size_t)nwaves);
       d_xslab = ws_get<float>(m->ws_xslab, tile_x * (size_t)nwaves);

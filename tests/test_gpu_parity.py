@@ -283,8 +283,9 @@ def test_random_ratings(kernel):
 # parity is checked at the order-independent level: the reference's own order-to-order
 # envelope at optTol 1e-7, the fixed point at a tight tolerance, optimality conditions.
 @pytest.mark.parametrize("KERNEL_TILE,cluster", [(KERNEL_TILE, 1), (KERNEL_TILE, 8),
-                                                 (KERNEL_TILE, 2), (KERNEL_TILE16, 1),
-                                                 (KERNEL_TILE16, 4)])
+                                                 (KERNEL_TILE, 2), (KERNEL_TILE, 16),
+                                                 (KERNEL_TILE16, 1), (KERNEL_TILE16, 4),
+                                                 (KERNEL_TILE16, 16)])
 def test_tile_kernel_ml100k(ml100k, ml_dev, ml_gpu, KERNEL_TILE, cluster):
     """cluster = workgroups sharing one tile (users split in `cluster` ranges, one
     all-reduce of the partial dots per visit)."""
