@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 --pmc passes of the default bench into profiles/pmc_traffic.json.
+
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d D1 -o c4 -- python bench.py --warmup 0 --steps 1 --cpu-seconds 0
+  rocprofv3 --pmc WRITE_SIZE ... -d D2 ...
+  rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE ... -- scripts/micro/gather_bw c      (calibration, known bytes)
+  python scripts/pmc_to_json.py D1/c4_counter_collection.csv D2/c4_counter_collection.csv \
+         CAL_FETCH.csv CAL_WRITE.csv BENCH.json
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes
+(MI355X_MICROARCH.md, HBM section); the correction factors are taken from the calibration
+launches, which move a known number of bytes in the tile kernel's access pattern (random
+whole 128-byte lines).
+"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counter(path, kernel_substr, name):
+    tot, launches, secs = 0.0, 0, []
+    for row in csv.DictReader(open(path)):
+        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == name:
+            tot += float(row["Counter_Value"])
+            launches += 1
+            secs.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9)
+    return tot, launches, secs
+
+
+def main():
+    fetch_csv, write_csv, cal_f, cal_w, bench_json = sys.argv[1:6]
+    known = 256.0 * 16 * 1000 * 16 * 256.0  # gather_bw c: bytes per calibration launch
+    gf, _, _ = counter(cal_f, "gather<128", "FETCH_SIZE")
+    sw, _, _ = counter(cal_w, "scatter<128", "WRITE_SIZE")
+    sf, _, _ = counter(cal_f, "scatter<128", "FETCH_SIZE")
+    fcorr, wcorr = known / (gf * 1024), known / (sw * 1024)
+    f, nf, tf = counter(fetch_csv, "cd_tile_kernel", "FETCH_SIZE")
+    w, nw, tw = counter(write_csv, "cd_tile_kernel", "WRITE_SIZE")
+    bench = json.load(open(bench_json))
+    cfg = bench["config"]
+    entry = {
+        "match": {"workload": cfg["workload"].split(" ")[0], "scale": cfg["scale"],
+                  "columns_per_step_per_gpu": cfg["columns_per_step_per_gpu"],
+                  "kernel": cfg["kernel"], "binary": "binary values" in cfg["workload"]},
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- "
+                   "python bench.py --warmup 0 --steps 1 --cpu-seconds 0 (one pass per counter)",
+        "launches": nf, "FETCH_SIZE_kb": f / max(nf, 1), "WRITE_SIZE_kb": w / max(nw, 1),
+        "calibration": {"known_bytes_per_launch": known, "gather128_FETCH_SIZE_kb": gf,
+                        "scatter128_WRITE_SIZE_kb": sw, "scatter128_FETCH_SIZE_kb": sf},
+        "fetch_correction": round(fcorr, 4), "write_correction": round(wcorr, 4),
+        "traffic_bytes_per_launch": (f / max(nf, 1)) * 1024 * fcorr + (w / max(nw, 1)) * 1024 * wcorr,
+        "kernel_seconds_under_pmc": [round(x, 2) for x in tf + tw],
+        "alg_bytes_per_launch_same_run": bench["roofline"]["alg_bytes_per_launch"],
+    }
+    out = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    json.dump({"entries": [entry]}, open(out, "w"), indent=1)
+    print(json.dumps(entry, indent=1))
+
+
+if __name__ == "__main__":
+    main()

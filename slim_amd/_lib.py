@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslim.so")
+# SLIM_AMD_LIB points at another build of the same library (A/B comparisons of kernels)
+LIB_PATH = os.environ.get("SLIM_AMD_LIB") or os.path.join(_HERE, "libslim.so")
 
 f64_1d = np.ctypeslib.ndpointer(dtype=np.float64, ndim=1, flags="C_CONTIGUOUS")
 f32_1d = np.ctypeslib.ndpointer(dtype=np.float32, ndim=1, flags="C_CONTIGUOUS")
@@ -108,6 +109,8 @@ def load():
             "g.build()'` (hipcc, gfx950). There is no CPU fallback for SLIM training." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
+        if os.environ.get("SLIM_AMD_LIB") and not hasattr(lib, name):
+            continue  # an older build used for an A/B run may lack the newest entry points
         fn = getattr(lib, name)  # AttributeError here = ABI drift, fail loudly
         fn.restype = res
         fn.argtypes = args

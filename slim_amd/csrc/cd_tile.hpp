@@ -141,33 +141,37 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
     const int par = (int)(epoch & 1u);
     if (wave == 0) {
       if (lane < P) gran_store(mbox + (par * kTileKMax + mk) * P + lane, epoch, v);
-      constexpr int MAXG = kTileKMax / SL;  // granules per lane: members slot, slot+SL, ...
-      tile_gran_t g[MAXG];
-      uint64_t t0 = 0;
-      bool aborted = s_abort != 0;
-      for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < MAXG; ++j) {
-          const int kk = slot + j * SL;
-          g[j] = kk < K ? gran_load(mbox + (par * kTileKMax + kk) * P + q)
-                        : ((tile_gran_t)epoch << 32);
-        }
-#pragma unroll
-        for (int j = 0; j < MAXG; ++j) ok &= (uint32_t)(g[j] >> 32) == epoch;
-        if (__all(ok) || aborted) break;
-        if (t0 == 0) t0 = wall_clock64();
-        __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > 1000000000ull) {  // 10 s at 100 MHz: give up, loudly
-          aborted = true;
-          s_abort = 1;
-          atomicExch(S.overflow, 2);
-        }
-      }
+      // every lane polls the granules of members slot, slot+SL, ...: four per round trip
+      // (one batch covers clusters of up to 4*SL members, larger ones take two batches)
+      constexpr int MAXG = 4;
       float tot = 0.0f;
+      bool aborted = s_abort != 0;
+      for (int kb = 0; kb < K; kb += MAXG * SL) {
+        tile_gran_t g[MAXG];
+        uint64_t t0 = 0;
+        for (;;) {
+          bool ok = true;
 #pragma unroll
-      for (int j = 0; j < MAXG; ++j)
-        if (slot + j * SL < K) tot += __uint_as_float((uint32_t)g[j]);
+          for (int j = 0; j < MAXG; ++j) {
+            const int kk = kb + slot + j * SL;
+            g[j] = kk < K ? gran_load(mbox + (par * kTileKMax + kk) * P + q)
+                          : ((tile_gran_t)epoch << 32);
+          }
+#pragma unroll
+          for (int j = 0; j < MAXG; ++j) ok &= (uint32_t)(g[j] >> 32) == epoch;
+          if (__all(ok) || aborted) break;
+          if (t0 == 0) t0 = wall_clock64();
+          __builtin_amdgcn_s_sleep(1);
+          if (wall_clock64() - t0 > 1000000000ull) {  // 10 s at 100 MHz: give up, loudly
+            aborted = true;
+            s_abort = 1;
+            atomicExch(S.overflow, 2);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXG; ++j)
+          if (kb + slot + j * SL < K) tot += __uint_as_float((uint32_t)g[j]);
+      }
       if (SL == 4) tot += __shfl_xor(tot, 16);
       tot += __shfl_xor(tot, 32);
       if (lane < P) s_tot[par][q] = tot;
@@ -346,11 +350,6 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
       return clock64();
     };
 
-    // ids/values of the NEXT visit's first block, fetched before this visit's barrier and
-    // cluster exchange so that the next gather can start as soon as the update is out
-    int pf_id = 0, pf_n = 0, pf_col = -1;
-    float pf_v = 0.0f;
-
     const char* __restrict__ rb = reinterpret_cast<const char*>(r);
     char* __restrict__ rbw = reinterpret_cast<char*>(r);
     const uint32_t qoff = (uint32_t)q << 2;
@@ -360,7 +359,7 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
     // [s, e) is this member's slice of column i, len the length of the whole column
     auto visit = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
                      const float xi, const float cn, const float sq, const bool live, float& dlt,
-                     const int mode, const int nxt_i, const int64_t nxt_s, const int64_t nxt_e) {
+                     const int mode) {
       const bool part = live && tile_active(xi);
       if (!__any(part)) return;
       constexpr int64_t CH = 64 * NW;  // nnz per workgroup chunk
@@ -418,33 +417,13 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
       const uint64_t p0 = tick();
       float acc = 0.0f;
       int64_t c0 = s;
-      bool have_first = pf_col == i;  // first block already fetched by the previous visit
       for (; c0 + CH < e; c0 += CH) {
-        if (have_first) {
-          idreg = pf_id; vreg = pf_v; nhere = pf_n;
-          have_first = false;
-        } else {
-          load_ids(c0);
-        }
+        load_ids(c0);
         gather();
         if (mode == 0) acc += dot_block();
       }
-      if (have_first) {
-        idreg = pf_id; vreg = pf_v; nhere = pf_n;
-      } else {
-        load_ids(c0);  // last chunk: kept in registers for the update
-      }
+      load_ids(c0);  // last chunk: kept in registers for the update
       gather();
-      pf_col = -1;
-      if (nxt_i >= 0) {  // issue the next visit's first block now; it lands under the
-        const int64_t b0 = nxt_s + 64 * wave;  // barrier / exchange / update below
-        const int64_t left = nxt_e - b0;
-        pf_n = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
-        const bool okn = lane < pf_n;
-        pf_id = okn ? ci[b0 + lane] - ubase : 0;
-        pf_v = okn ? (HAS_VAL ? cv[b0 + lane] : 1.0f) : 0.0f;
-        pf_col = nxt_i;
-      }
       const uint64_t p1 = tick();
 
       float d = 0.0f, nx = xi;
@@ -510,7 +489,7 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
         const int i = uni(ul[p]);
         const int64_t* sp = csplit + (int64_t)i * (K + 1);
         visit(i, uni(sp[mk]), uni(sp[mk + 1]), uni(sp[K]) - uni(sp[0]), x[(int64_t)i * P + q],
-              0.0f, 0.0f, !done_q, unused, 1, -1, 0, 0);
+              0.0f, 0.0f, !done_q, unused, 1);
       }
     }
 
@@ -525,38 +504,30 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
       float dlt = 0.0f;
       const PermCtx pc = perm_make((uint32_t)nunion, perm_key(S.seed, (uint32_t)grp, (uint32_t)t));
       if (nunion > 0) {
-        // software pipeline on the visit scalars: column ids are read three visits ahead,
-        // slice offsets / x row / norms two visits ahead, so that at visit p the scalars of
-        // p and p+1 are already in registers (values stay in VGPRs until consumed)
-        struct Meta { int i; int64_t s; int n, len; float xi, cn, sq; };
-        auto load_meta = [&](const int iraw) -> Meta {
-          Meta m;
-          const int64_t* sp = csplit + (int64_t)iraw * (K + 1);
-          m.i = iraw;
-          m.s = sp[mk];
-          m.n = (int)(sp[mk + 1] - m.s);
-          m.len = (int)(sp[K] - sp[0]);
-          m.xi = x[(int64_t)iraw * P + q];
-          m.cn = A.cnorm[iraw];
-          m.sq = A.csq[iraw];
-          return m;
-        };
-        Meta mA = load_meta(ul[perm_index(pc, 0u)]);
-        Meta mB = mA;
-        if (nunion > 1) mB = load_meta(ul[perm_index(pc, 1u)]);
-        int i_c = nunion > 2 ? ul[perm_index(pc, 2u)] : 0;
+        // software pipeline on the visit scalars: the column id is read two visits ahead, the
+        // slice offsets / x row / norms one visit ahead (values stay in VGPRs until consumed)
+        int i_n1 = ul[perm_index(pc, 0u)];
+        int i_n2 = nunion > 1 ? ul[perm_index(pc, 1u)] : 0;
+        const int64_t* sp0 = csplit + (int64_t)i_n1 * (K + 1);
+        int64_t s_n = sp0[mk];
+        int n_n = (int)(sp0[mk + 1] - s_n), l_n = (int)(sp0[K] - sp0[0]);
+        float xi_n = x[(int64_t)i_n1 * P + q], cn_n = A.cnorm[i_n1], sq_n = A.csq[i_n1];
         for (int p = 0; p < nunion; ++p) {
-          const int i = uni(mA.i);
-          const int64_t s = uni(mA.s), e = s + uni(mA.n);
-          const int64_t len = uni(mA.len);
-          const float xi = mA.xi, cn = uni(mA.cn), sq = uni(mA.sq);
-          mA = mB;  // visit p+1: loaded one visit ago
-          if (p + 2 < nunion) mB = load_meta(i_c);
-          if (p + 3 < nunion) i_c = ul[perm_index(pc, (uint32_t)(p + 3))];
-          const bool has_next = p + 1 < nunion;
-          const int64_t ns = has_next ? uni(mA.s) : 0;
-          visit(i, s, e, len, xi, cn, sq, live, dlt, 0, has_next ? uni(mA.i) : -1, ns,
-                has_next ? ns + uni(mA.n) : 0);
+          const int i = uni(i_n1);
+          const int64_t s = uni(s_n), e = s + uni(n_n), len = uni(l_n);
+          const float xi = xi_n, cn = uni(cn_n), sq = uni(sq_n);
+          if (p + 1 < nunion) {
+            i_n1 = i_n2;
+            const int64_t* spn = csplit + (int64_t)i_n1 * (K + 1);
+            s_n = spn[mk];
+            n_n = (int)(spn[mk + 1] - s_n);
+            l_n = (int)(spn[K] - spn[0]);
+            xi_n = x[(int64_t)i_n1 * P + q];
+            cn_n = A.cnorm[i_n1];
+            sq_n = A.csq[i_n1];
+            if (p + 2 < nunion) i_n2 = ul[perm_index(pc, (uint32_t)(p + 2))];
+          }
+          visit(i, s, e, len, xi, cn, sq, live, dlt, 0);
         }
       }
       if (live && dlt < S.opt_tol) {  // cd.c:135-138
