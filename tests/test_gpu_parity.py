@@ -520,3 +520,38 @@ def test_output_arena_overflow_is_recovered(ml100k, ml_gpu, monkeypatch):
     assert abs(W.nnz - ml_gpu[0].nnz) <= 60 and maxdiff(W, ml_gpu[0]) <= 3e-3
     assert abs(st["objval"] - ml_gpu[1]["objval"]) <= 1e-4 * st["objval"]
     m.close()
+
+
+# ---- the large-matrix path at a realistic shape: size-independent properties --------------------
+def test_tile_clusters_kkt_on_synthetic_c4_shape():
+    """A 1/10-scale copy of BASELINE.json configs[3] (100K users x 10K items, ~9M nnz, binary):
+    the tile kernel with clusters must return, for every solved item column, a point that
+    satisfies the optimality conditions of the elastic-net NNLS -- no oracle involved:
+      x_i > 0  =>  a_i.(y - Ax) - l2 x_i = l1 ;  x_i = 0, i != iC  =>  a_i.(y - Ax) <= l1."""
+    import torch
+    from slim_amd import synth
+    nr, nc, nz = synth.scaled("c4", 0.1)
+    ptr, ind, val = synth.generate_csr(nr, nc, nz, seed=5, device="cpu")
+    R = sp.csr_matrix((val.numpy(), ind.numpy(), ptr.numpy()), shape=(nr, nc))
+    m = DeviceMatrix.from_scipy(R, binary=True)
+    b, e = 1000, 1000 + 256
+    for cl in (0, 4):  # automatic and explicit cluster sizes
+        W, st = m.learn(l1r=1.0, l2r=1.0, optTol=1e-12, niters=100000, col_begin=b, col_end=e,
+                        **({"cluster": cl} if cl else {}))
+        assert st["kernel"] == KERNEL_TILE and W.nnz > 0
+        X = sp.csc_matrix(W)[:, b:e]
+        assert X.data.min() > 0 and X[np.arange(b, e), np.arange(e - b)].nnz == 0   # x >= 0, diag 0
+        Rc = R.tocsc()
+        resid = (Rc[:, b:e] - R @ X).toarray().astype(np.float64)      # y - A x, nrows x 256
+        grad = (R.T @ resid)                                              # ncols x 256
+        Xd = X.toarray().astype(np.float64)
+        pos = Xd > 0
+        assert np.abs((grad - Xd)[pos] - 1.0).max() <= 5e-3
+        off = ~pos
+        off[np.arange(b, e), np.arange(e - b)] = False
+        assert (grad[off] <= 1.0 + 5e-3).all()
+    # the same columns through the one-wavefront-per-item kernel: same fixed point
+    Wh, _ = m.learn(l1r=1.0, l2r=1.0, optTol=1e-12, niters=100000, col_begin=b, col_end=e,
+                    kernel=KERNEL_WAVE_HBM)
+    assert maxdiff(Wh[:, b:e], W[:, b:e]) <= 5e-5
+    m.close()
