@@ -101,8 +101,11 @@ enum {
   SLIM_OPTION_GPU_SEED = 13,     /* seed of the visiting permutation [1]       */
   SLIM_OPTION_GPU_DEVICE = 14,   /* HIP device ordinal [current device]        */
   SLIM_OPTION_GPU_KERNEL = 15,   /* slimgpu_kernel_et [SLIMGPU_KERNEL_AUTO]    */
-  SLIM_OPTION_GPU_CLUSTER = 16   /* tile kernels: workgroups sharing one tile,
-                                    1/2/4/8/16 [auto: by tiles per cluster]            */
+  SLIM_OPTION_GPU_CLUSTER = 16,  /* tile kernels: workgroups sharing one tile,
+                                    1/2/4/8/16/32 [auto: by tiles per cluster] */
+  SLIM_OPTION_GPU_HEAVYTILES = 17,   /* tile kernels: the N most expensive tiles are
+                                        solved first by larger clusters [auto]; 0 = off */
+  SLIM_OPTION_GPU_HEAVYCLUSTER = 18  /* size of those clusters, 2..32 [auto]          */
 };
 
 typedef enum {

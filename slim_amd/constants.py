@@ -44,6 +44,8 @@ class Opt(enum.IntEnum):
     GPU_DEVICE = 14     # HIP device ordinal (default: current device)
     GPU_KERNEL = 15     # kernel selection, see slim_gpu.h (default auto)
     GPU_CLUSTER = 16    # tile kernels: workgroups per tile (default auto)
+    GPU_HEAVYTILES = 17    # tile kernels: most expensive tiles solved first by larger clusters
+    GPU_HEAVYCLUSTER = 18  # ... of this many workgroups (default auto)
 
 
 for _o in Opt:

@@ -62,7 +62,7 @@
 namespace slimamd {
 
 constexpr int kTileNW = 16;  // wavefronts per workgroup (default geometry)
-constexpr int kTileKMax = 16;  // largest cluster (workgroups sharing one tile)
+constexpr int kTileKMax = 32;  // largest cluster (workgroups sharing one tile)
 constexpr float kInactive = -__builtin_huge_valf();
 __device__ __forceinline__ bool tile_active(float xv) { return xv > -3.0e38f; }
 
@@ -79,14 +79,13 @@ __device__ __forceinline__ tile_gran_t gran_load(const tile_gran_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// PROFILE adds s_memtime stamps around the phases of a visit (SLIM_GPU_TRACE=2); the
-// waits it needs perturb the schedule a little, so it is a separate instantiation.
-// NW = wavefronts per workgroup: 16 (one workgroup per CU) or 8 (two per CU, whose phases
-// -- gather / barrier / cluster exchange / write-back -- then overlap).
-// (16 wavefronts per CU either way: the second launch bound, 4 waves per SIMD, caps the
-// kernel at 128 VGPRs)
-template <int P, bool HAS_VAL, bool PROFILE, int NW>
-__global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
+// One phase of a launch.  HI = the heavy phase: clusters of S.cluster_hi workgroups on the
+// first S.nheavy tiles of the work list; otherwise clusters of S.cluster on the rest.  The
+// phase is a template parameter so that the cluster geometry stays a function of kernel
+// arguments (re-derivable, no live registers across the visit loop).  Returns false when
+// the launch was aborted.
+template <int P, bool HAS_VAL, bool PROFILE, int NW, bool HI>
+__device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& S, uint32_t& epoch) {
   constexpr int NT = 64 * NW;  // threads per workgroup
   constexpr int SL = 64 / P;       // users per wavefront step (lane groups)
   constexpr int STEPS = 64 / SL;   // steps per 64-nnz block (== P)
@@ -110,18 +109,21 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
 
   // cluster geometry: K consecutive workgroups share tiles, member mk owns users
   // [ubase, uend)
-  const int K = S.cluster;
+  const int K = HI ? S.cluster_hi : S.cluster;
   const int cid = (int)blockIdx.x / K, mk = (int)blockIdx.x % K;
-  const int ubase = S.ubounds[mk], uend = S.ubounds[mk + 1];
-  tile_gran_t* const mbox = S.mailbox + (int64_t)cid * (2 * kTileKMax * P + 8);
-  float* aty_sh = S.atyshared ? S.atyshared + (int64_t)cid * S.x_stride : nullptr;  // cluster aTy
-  uint32_t epoch = 0;
+  const int32_t* __restrict__ ubounds = HI ? S.ubounds_hi : S.ubounds;
+  const int ubase = ubounds[mk], uend = ubounds[mk + 1];
+  tile_gran_t* const mbox = (HI ? S.mailbox_hi : S.mailbox) + (int64_t)cid * (2 * kTileKMax * P + 8);
+  // cluster aTy accumulator
+  float* const aty_base = HI ? S.atyshared_hi : S.atyshared;
+  float* const aty_sh = aty_base ? aty_base + (int64_t)cid * S.x_stride : nullptr;
+  const int64_t* __restrict__ csplit = HI ? S.csplit_hi : S.csplit;  // [ncols][K+1] slice boundaries
+  const int grp_end = HI ? S.nheavy : S.ngroups;
   if (tid == 0) s_abort = 0;
   float* __restrict__ r = S.slab + (int64_t)blockIdx.x * S.slab_stride;   // [my users][P]
   float* x = S.xslab + (int64_t)blockIdx.x * S.x_stride;                 // [ncols][P]
   int* __restrict__ ul = S.ulist + (int64_t)blockIdx.x * S.u_stride;      // union list
   const int64_t* __restrict__ colptr = A.colptr;
-  const int64_t* __restrict__ csplit = S.csplit;  // [ncols][K+1] slice boundaries
   const int32_t* __restrict__ ci = A.colind;
   const float* __restrict__ cv = A.colval;
 
@@ -200,12 +202,13 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
     // member 0 pulls the next tile and tells the others
     if (tid == 0) {
       int gnext = 0;
-      if (mk == 0) gnext = atomicAdd(S.queue, 1);
+      if (mk == 0) gnext = HI ? atomicAdd(S.queue_hi, 1) : S.nheavy + atomicAdd(S.queue, 1);
       s_grp = gnext;
     }
     __syncthreads();
     const int grp = (int)(cluster_sum(mk == 0 ? (float)s_grp : 0.0f) + 0.5f);
-    if (grp >= S.ngroups || s_abort) break;
+    if (s_abort) return false;
+    if (grp >= grp_end) break;
     const uint64_t t_start = wall_clock64();
     const int base = grp * P;
     const int nprob = (S.nwork - base) < P ? (S.nwork - base) : P;
@@ -357,9 +360,17 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
     // One coordinate: dot for the P problems, update, residual axpy.
     // mode 0: CD visit; mode 1: fold the warm-start coefficients into r (cd.c:108-110)
     // [s, e) is this member's slice of column i, len the length of the whole column
+    // HI (latency-bound: slices of a few hundred nnz): the ids of the next visit's first
+    // block are requested while this visit waits for the cluster, [sn_v, sn_v + nn_v) = that
+    // slice
+    int pf_id = 0;
+    float pf_v = 0.0f;
+    int64_t pf_at = -1;  // slice start the prefetched block belongs to (-1: none)
     auto visit = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
                      const float xi, const float cn, const float sq, const bool live, float& dlt,
-                     const int mode) {
+                     const int mode, const int64_t sn_v, const int nn_v) {
+      int64_t pf_here = pf_at;  // valid for the first load of the first block only
+      pf_at = -1;
       const bool part = live && tile_active(xi);
       if (!__any(part)) return;
       constexpr int64_t CH = 64 * NW;  // nnz per workgroup chunk
@@ -373,8 +384,14 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
         const int64_t left = e - b0;
         nhere = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
         const bool ok = lane < nhere;
-        idreg = ok ? ci[b0 + lane] - ubase : 0;
-        vreg = ok ? (HAS_VAL ? cv[b0 + lane] : 1.0f) : 0.0f;
+        if (HI && c0 == pf_here) {  // requested during the previous visit
+          idreg = pf_id;
+          vreg = pf_v;
+          pf_here = -1;  // (pf_id is reused for the next visit before this block is re-read)
+        } else {
+          idreg = ok ? ci[b0 + lane] - ubase : 0;
+          vreg = ok ? (HAS_VAL ? cv[b0 + lane] : 1.0f) : 0.0f;
+        }
       };
       // gather the residual lines of the block: STEPS loads per lane in flight
       auto gather = [&]() {
@@ -424,6 +441,15 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
       }
       load_ids(c0);  // last chunk: kept in registers for the update
       gather();
+      // (sn_v / nn_v are still in flight when the visit starts: made uniform only here)
+      const int64_t sn = HI ? uni(sn_v) : 0, en = HI ? sn + uni(nn_v) : 0;
+      if (HI && S.hi_prefetch && mode == 0 && en > sn) {
+        const int64_t b0 = sn + 64 * wave;
+        const bool ok = b0 + lane < en;
+        pf_id = ok ? ci[b0 + lane] - ubase : 0;
+        pf_v = ok ? (HAS_VAL ? cv[b0 + lane] : 1.0f) : 0.0f;
+        pf_at = sn;
+      }
       const uint64_t p1 = tick();
 
       float d = 0.0f, nx = xi;
@@ -489,7 +515,7 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
         const int i = uni(ul[p]);
         const int64_t* sp = csplit + (int64_t)i * (K + 1);
         visit(i, uni(sp[mk]), uni(sp[mk + 1]), uni(sp[K]) - uni(sp[0]), x[(int64_t)i * P + q],
-              0.0f, 0.0f, !done_q, unused, 1);
+              0.0f, 0.0f, !done_q, unused, 1, 0, 0);
       }
     }
 
@@ -527,7 +553,8 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
             sq_n = A.csq[i_n1];
             if (p + 2 < nunion) i_n2 = ul[perm_index(pc, (uint32_t)(p + 2))];
           }
-          visit(i, s, e, len, xi, cn, sq, live, dlt, 0);
+          const bool more = p + 1 < nunion;
+          visit(i, s, e, len, xi, cn, sq, live, dlt, 0, s_n, more ? n_n : 0);
         }
       }
       if (live && dlt < S.opt_tol) {  // cd.c:135-138
@@ -626,6 +653,7 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
       tr[3] = wall_clock64();
       tr[4] = blockIdx.x;
       tr[5] = (uint64_t)nunion;
+      tr[6] = (uint64_t)K;
       if (PROFILE) {
         uint64_t* pr = S.trace + (int64_t)S.ngroups * 8 + (int64_t)grp * 8;
         for (int k = 0; k < 7; ++k) pr[k] = prof[k];
@@ -633,6 +661,25 @@ __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, 
     }
     __syncthreads();
   }
+  return true;
+}
+
+// PROFILE adds s_memtime stamps around the phases of a visit (SLIM_GPU_TRACE=2); the
+// waits it needs perturb the schedule a little, so it is a separate instantiation.
+// NW = wavefronts per workgroup: 16 (one workgroup per CU) or 8 (two per CU, whose phases
+// -- gather / barrier / cluster exchange / write-back -- then overlap).
+// (16 wavefronts per CU either way: the second launch bound, 4 waves per SIMD, caps the
+// kernel at 128 VGPRs)
+template <int P, bool HAS_VAL, bool PROFILE, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
+  uint32_t epoch = 0;
+  // heavy phase first: whole clusters of S.cluster_hi only (S.cluster divides S.cluster_hi,
+  // so the workgroups of a big cluster regroup into whole small ones afterwards)
+  if (S.nheavy > 0 && (int)blockIdx.x < ((int)gridDim.x / S.cluster_hi) * S.cluster_hi) {
+    if (!tile_phase<P, HAS_VAL, PROFILE, NW, true>(A, S, epoch)) return;
+    __syncthreads();
+  }
+  tile_phase<P, HAS_VAL, PROFILE, NW, false>(A, S, epoch);
 }
 
 }  // namespace slimamd

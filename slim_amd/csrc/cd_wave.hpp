@@ -81,6 +81,17 @@ struct SolveArgs {
   const int64_t* csplit;         // [ncols][K+1] column slice boundaries (K = 1: colptr pairs)
   unsigned long long* mailbox;   // per cluster: 2 x 8 x P granules (+8), zeroed per launch
   float* atyshared;              // per cluster: [ncols][P] aTy accumulator (K > 1)
+  // heavy-tile phase: the first nheavy tiles of the work list (the most expensive ones) are
+  // solved by clusters of cluster_hi workgroups before the launch regroups into clusters
+  // of `cluster` (cluster divides cluster_hi, so the small clusters nest in the big ones)
+  int32_t nheavy;                // 0: no heavy phase
+  int32_t cluster_hi;
+  const int32_t* ubounds_hi;
+  const int64_t* csplit_hi;
+  unsigned long long* mailbox_hi;
+  float* atyshared_hi;
+  int32_t* queue_hi;
+  int32_t hi_prefetch;           // heavy phase: request the next visit's ids early
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;
   int64_t* out_off;

@@ -45,9 +45,9 @@ struct slimgpu_matrix {
   std::vector<int64_t> h_cost;  // scheduling proxy per column (Gram work G)
   std::vector<int64_t> h_rowptr;  // host copy, fetched on first clustered solve
   // column slice boundaries for tile clusters of size K (index log2 K), built on demand
-  int32_t* d_ubounds[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int64_t* d_csplit[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int32_t max_range_rows[5] = {0, 0, 0, 0, 0};
+  int32_t* d_ubounds[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t* d_csplit[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int32_t max_range_rows[6] = {0, 0, 0, 0, 0, 0};
   double setup_ms = 0;
   int num_cus = 256;
   // workspace reused by successive solves
@@ -380,6 +380,8 @@ LearnOptions decode_options(const int32_t* io, const double* dopt) {
   o.device = geti(SLIM_OPTION_GPU_DEVICE, -1);
   o.kernel = geti(SLIM_OPTION_GPU_KERNEL, SLIMGPU_KERNEL_AUTO);
   o.cluster = geti(SLIM_OPTION_GPU_CLUSTER, 0);
+  o.heavy_tiles = geti(SLIM_OPTION_GPU_HEAVYTILES, -1);
+  o.heavy_cluster = geti(SLIM_OPTION_GPU_HEAVYCLUSTER, 0);
   return o;
 }
 
@@ -631,13 +633,14 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int nwaves = std::max(1, std::min(nwork, m->num_cus * waves_per_cu));
     size_t tile_r = 0, tile_x = 0, tile_u = 0;
     int clusterK = 1, cluster_lg = 0, nclusters = 0;
+    int clusterHi = 0, hi_lg = 0, nheavy = 0, nclusters_hi = 0, auto_heavy = 0;
     const int wg_slots = m->num_cus * (16 / tileNW);  // co-resident tile workgroups
     if (use_tile) {
       const int ngroups_all = (nwork + tileP - 1) / tileP;
       // cluster size: share a tile among K workgroups when there are too few tiles to keep
       // every CU busy behind the slowest one (auto), or as requested
       if (opt.cluster == 1 || opt.cluster == 2 || opt.cluster == 4 || opt.cluster == 8 ||
-          opt.cluster == 16) {
+          opt.cluster == 16 || opt.cluster == 32) {
         clusterK = opt.cluster;
       } else {
         // the heaviest tile runs ~7x the median (popular items need more sweeps): a
@@ -646,8 +649,26 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         // ... but a member's slice of a column should stay long enough (>= ~512 nnz on
         // average) for the gather to amortise the per-visit exchange
         int cap = 1;
-        while (cap < kTileKMax && (m->nnz / std::max(ncols, 1)) / (2 * cap) >= 512) cap *= 2;
-        while (clusterK < cap && (int64_t)ngroups_all * clusterK < 8 * (int64_t)wg_slots)
+        while (cap < 16 && (m->nnz / std::max(ncols, 1)) / (2 * cap) >= 512) cap *= 2;
+        // heavy tiles (queue order = cost order): a few tiles of the most popular items run
+        // 5-8x the median (measured on C4: 52 / 36 / 29 s against 6.4 s).  They go to big
+        // clusters first (below), which lets everything else use small, efficient clusters:
+        // clusters of 2-4 reach ~0.9 of the HBM roofline, clusters of 8 pay ~25 % for the
+        // per-visit exchange.  Cost is only a proxy for time, so the test is generous (a
+        // light tile solved by a big cluster wastes a few CU-seconds, a heavy one solved by
+        // a small cluster is the critical path of the launch).
+        if (opt.heavy_tiles < 0 && tileNW == 16 && ngroups_all >= 16) {
+          auto tile_cost = [&](int gI) {
+            int64_t c = 0;
+            for (int t = gI * tileP; t < std::min((gI + 1) * tileP, nwork); ++t)
+              c += m->h_cost[order[(size_t)t]];
+            return c;
+          };
+          const int64_t med = tile_cost(ngroups_all / 2);
+          while (auto_heavy < ngroups_all / 16 && tile_cost(auto_heavy) >= 12 * med) ++auto_heavy;
+        }
+        const int64_t fill = auto_heavy > 0 ? 4 : 8;  // tiles wanted per workgroup slot
+        while (clusterK < cap && (int64_t)ngroups_all * clusterK < fill * (int64_t)wg_slots)
           clusterK *= 2;
       }
       while (clusterK > 1 && wg_slots / clusterK < 1) clusterK /= 2;
@@ -657,14 +678,37 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       tile_x = (size_t)ncols_pad * tileP;
       tile_u = (size_t)ncols_pad;
       nclusters = std::max(1, std::min(ngroups_all, wg_slots / clusterK));
+      // heavy phase: the first nheavy tiles (most expensive) go to clusters of clusterHi
+      nheavy = std::min(opt.heavy_tiles < 0 ? auto_heavy : opt.heavy_tiles, ngroups_all);
+      clusterHi = opt.heavy_cluster;
+      if (const char* e = std::getenv("SLIM_GPU_HEAVY")) {  // "tiles,cluster" (experiments)
+        int a = 0, b = 0;
+        if (std::sscanf(e, "%d,%d", &a, &b) == 2) {
+          nheavy = std::min(std::max(a, 0), ngroups_all);
+          clusterHi = b;
+        }
+      }
+      if (clusterHi != 2 && clusterHi != 4 && clusterHi != 8 && clusterHi != 16 && clusterHi != 32)
+        clusterHi = std::max(16, std::min(4 * clusterK, kTileKMax));
+      if (clusterHi <= clusterK || nclusters * clusterK < clusterHi) nheavy = 0;
+      if (nheavy > 0) {
+        for (hi_lg = 0; (1 << hi_lg) < clusterHi; ++hi_lg) {}
+        ensure_cluster_split(m, hi_lg);
+        nclusters_hi = nclusters * clusterK / clusterHi;
+        tile_r = std::max(tile_r, (size_t)round_up(m->max_range_rows[hi_lg], 64) * tileP);
+      }
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
       const size_t per_cl = ((tile_r + tile_x) * sizeof(float) + tile_u * sizeof(int32_t)) * clusterK +
-                            (clusterK > 1 ? tile_x * sizeof(float) : 0);
+                            (clusterK > 1 || nheavy > 0 ? tile_x * sizeof(float) : 0);
       const size_t have = free_b + m->ws_slab.bytes + m->ws_xslab.bytes + m->ws_ulist.bytes +
                           m->ws_atysh.bytes;
       const size_t budget = have > (size_t(6) << 30) ? have - (size_t(6) << 30) : have / 2;
-      if ((size_t)nclusters * per_cl > budget) nclusters = (int)std::max<size_t>(1, budget / per_cl);
+      if ((size_t)nclusters * per_cl > budget) {
+        nclusters = (int)std::max<size_t>(1, budget / per_cl);
+        nclusters_hi = nclusters * clusterK / std::max(clusterHi, 1);
+        if (nclusters_hi < 1) nheavy = 0;
+      }
       nwaves = nclusters * clusterK;  // workgroups launched
     }
 
@@ -676,20 +720,21 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int64_t* d_stl = ws_get<int64_t>(m->ws_stat_l, 3 * (size_t)ncols);
     float* d_stf = ws_get<float>(m->ws_stat_f, 2 * (size_t)ncols);
     // misc: [0] queue (int32) [1] overflow (int32) [2..3] cursor (u64)
-    int32_t* d_misc = ws_get<int32_t>(m->ws_misc, 4);
+    int32_t* d_misc = ws_get<int32_t>(m->ws_misc, 6);  // [4] queue of the heavy phase
     float* d_slab = nullptr;
     float* d_xslab = nullptr;
     int32_t* d_ulist = nullptr;
     unsigned long long* d_mailbox = nullptr;
     float* d_atysh = nullptr;
-    const size_t mailbox_words =
-        (size_t)std::max(nclusters, 1) * (2 * (size_t)kTileKMax * (size_t)tileP + 8);
+    const size_t mailbox_stride = 2 * (size_t)kTileKMax * (size_t)tileP + 8;
+    const size_t mailbox_words = (size_t)(std::max(nclusters, 1) + nclusters_hi) * mailbox_stride;
     if (use_tile) {
       d_slab = ws_get<float>(m->ws_slab, tile_r * (size_t)nwaves);
       d_xslab = ws_get<float>(m->ws_xslab, tile_x * (size_t)nwaves);
       d_ulist = ws_get<int32_t>(m->ws_ulist, tile_u * (size_t)nwaves);
       d_mailbox = ws_get<unsigned long long>(m->ws_mailbox, mailbox_words);
-      if (clusterK > 1) d_atysh = ws_get<float>(m->ws_atysh, tile_x * (size_t)nclusters);
+      const size_t n_aty = (clusterK > 1 ? (size_t)nclusters : 0) + (nheavy > 0 ? (size_t)nclusters_hi : 0);
+      if (n_aty > 0) d_atysh = ws_get<float>(m->ws_atysh, tile_x * n_aty);
     } else if (!use_lds) {
       d_slab = ws_get<float>(m->ws_slab, vec_floats * (size_t)nwaves);
     }
@@ -762,7 +807,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       float* d_av = ws_get<float>(m->ws_arena_v, (size_t)arena_cap);
       HIP_TRY(hipMemcpyAsync(d_order, pending.data(), sizeof(int32_t) * (size_t)npend,
                              hipMemcpyHostToDevice, stream));
-      HIP_TRY(hipMemsetAsync(d_misc, 0, sizeof(int32_t) * 4, stream));
+      HIP_TRY(hipMemsetAsync(d_misc, 0, sizeof(int32_t) * 6, stream));
+      if (attempt > 0) nheavy = 0;  // a retry regroups what is left: plain clusters
 
       SolveArgs S;
       S.l1 = (float)opt.l1r;
@@ -792,7 +838,16 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.ubounds = use_tile ? m->d_ubounds[cluster_lg] : nullptr;
       S.csplit = use_tile ? m->d_csplit[cluster_lg] : nullptr;
       S.mailbox = d_mailbox;
-      S.atyshared = d_atysh;
+      S.atyshared = clusterK > 1 ? d_atysh : nullptr;
+      S.nheavy = use_tile ? nheavy : 0;
+      S.cluster_hi = clusterHi;
+      S.ubounds_hi = nheavy > 0 ? m->d_ubounds[hi_lg] : nullptr;
+      S.csplit_hi = nheavy > 0 ? m->d_csplit[hi_lg] : nullptr;
+      S.mailbox_hi = d_mailbox ? d_mailbox + (size_t)std::max(nclusters, 1) * mailbox_stride : nullptr;
+      S.atyshared_hi = d_atysh ? d_atysh + (clusterK > 1 ? tile_x * (size_t)nclusters : 0) : nullptr;
+      S.queue_hi = d_misc + 4;
+      S.hi_prefetch = 1;
+      if (const char* e = std::getenv("SLIM_GPU_HI_PREFETCH")) S.hi_prefetch = std::atoi(e);
       if (use_tile)
         HIP_TRY(hipMemsetAsync(d_mailbox, 0, sizeof(unsigned long long) * mailbox_words, stream));
       const bool trace = use_tile && trace_level >= 1;
@@ -847,20 +902,34 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
           const uint64_t* e = &tr[8 * (size_t)gI];
           t0 = std::min(t0, e[0]);
           t1 = std::max(t1, e[3]);
-          busy += double(e[3] - e[0]);
-          setup += double(e[1] - e[0]);
-          sweeps += double(e[2] - e[1]);
+          const double wk = double(e[6]) / clusterK;  // heavy tiles occupy more workgroups
+          busy += double(e[3] - e[0]) * wk;
+          setup += double(e[1] - e[0]) * wk;
+          sweeps += double(e[2] - e[1]) * wk;
           dur.push_back(double(e[3] - e[0]) * 1e-5);
         }
         std::sort(dur.begin(), dur.end());
         const double span = double(t1 - t0);
         std::fprintf(stderr,
-                     "[trace] tiles %d on %d workgroups (clusters of %d): span %.2f ms (event %.2f ms), busy/"
+                     "[trace] tiles %d (%d heavy, clusters of %d) on %d workgroups (clusters of %d): span %.2f ms (event %.2f ms), busy/"
                      "(span*wgs) %.2f, setup %.1f%% sweeps %.1f%% of busy; tile ms min %.2f med "
                      "%.2f p90 %.2f max %.2f\n",
-                     S.ngroups, launch_waves, clusterK, span * 1e-5, ms,
+                     S.ngroups, S.nheavy, S.nheavy > 0 ? clusterHi : 0, launch_waves, clusterK, span * 1e-5, ms,
                      busy * clusterK / (span * launch_waves), 100 * setup / busy, 100 * sweeps / busy,
                      dur.front(), dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back());
+        if (S.ngroups >= 16) {  // queue order = cost order: (estimated cost, measured ms)
+          std::fprintf(stderr, "[trace] tile cost -> ms, queue order:");
+          for (int k = 0; k < 19; ++k) {
+            const int gI = k < 12 ? k : (int)((int64_t)S.ngroups * (k - 11) / 8) - (k == 19 ? 1 : 0);
+            if (gI >= S.ngroups) break;
+            double c = 0;
+            for (int t = gI * tileP; t < std::min((gI + 1) * tileP, (int)npend); ++t)
+              c += (double)m->h_cost[pending[(size_t)t]];
+            std::fprintf(stderr, " [%d] %.3g -> %.0f", gI, c,
+                         double(tr[8 * (size_t)gI + 3] - tr[8 * (size_t)gI]) * 1e-5);
+          }
+          std::fprintf(stderr, "\n");
+        }
         if (trace_level >= 2) {
           double ph[7] = {0, 0, 0, 0, 0, 0, 0};
           for (int gI = 0; gI < S.ngroups; ++gI)

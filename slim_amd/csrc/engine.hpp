@@ -18,6 +18,8 @@ struct LearnOptions {
   int32_t device = -1;  // -1: current
   int32_t kernel = SLIMGPU_KERNEL_AUTO;
   int32_t cluster = 0;  // tile-cluster size (0 = auto)
+  int32_t heavy_tiles = -1;   // tiles solved by big clusters first (-1 = auto, 0 = none)
+  int32_t heavy_cluster = 0;  // size of those clusters (0 = auto)
 };
 LearnOptions decode_options(const int32_t* ioptions, const double* doptions);
 

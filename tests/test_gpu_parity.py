@@ -324,6 +324,42 @@ def test_tile_kernel_ml100k(ml100k, ml_dev, ml_gpu, KERNEL_TILE, cluster):
     assert maxdiff(got[:, :200], Wt[:, :200]) <= 2e-5 and got[:, 200:].nnz == 0
 
 
+@pytest.mark.parametrize("cluster,heavy_tiles,heavy_cluster", [(2, 5, 8), (1, 3, 4), (4, 60, 32),
+                                                               (2, 1, 16)])
+def test_tile_kernel_heavy_phase(ml100k, ml_dev, cluster, heavy_tiles, heavy_cluster):
+    """The most expensive tiles are solved first by larger clusters, after which the launch
+    regroups into clusters of `cluster`; the result is the same walk of the same tiles."""
+    R, T = ml100k
+    W, st = ml_dev.learn(seed=1, kernel=KERNEL_TILE, cluster=cluster, heavy_tiles=heavy_tiles,
+                         heavy_cluster=heavy_cluster)
+    cs = ml_dev.column_stats()
+    Wo, so, err_o, obj_o = O.learn_cd_tile(R, tileP=32, seed=1, nthreads=8, return_stats=True)
+    assert maxdiff(W, Wo) <= 2e-5 and pattern_diff(W, Wo) <= 8
+    assert (cs.sweeps == so["sweeps"]).mean() >= 0.99
+    assert abs(cs.D.sum() - so["D"].sum()) <= 0.01 * so["D"].sum()
+    assert abs(st["objval"] - obj_o) <= 1e-4 * obj_o
+    assert np.array_equal(cs.G, so["G"])
+    ev = O.evaluate(W, R, T)
+    assert "%.4f" % ev["hr"] == "0.3191" and "%.4f" % ev["arhr"] == "0.1504"
+
+
+def test_tile_kernel_heavy_phase_long_slices():
+    """Column slices longer than a workgroup chunk (1024 nnz) in the heavy phase: the first
+    block's ids arrive by prefetch, later blocks and the re-read of the update do not."""
+    R = _random_ratings(60000, 96, 0.08, 11)   # ~4800 nnz per column
+    m = DeviceMatrix.from_scipy(R)
+    Wo, so, err_o, obj_o = O.learn_cd_tile(R, tileP=32, seed=3, nthreads=8, return_stats=True)
+    for cluster, heavy_tiles, heavy_cluster in ((1, 2, 2), (2, 1, 4), (1, 3, 4)):
+        W, st = m.learn(seed=3, kernel=KERNEL_TILE, cluster=cluster, heavy_tiles=heavy_tiles,
+                        heavy_cluster=heavy_cluster)
+        cs = m.column_stats()
+        assert maxdiff(W, Wo) <= 5e-5
+        assert (cs.sweeps == so["sweeps"]).mean() >= 0.98
+        assert abs(cs.D.sum() - so["D"].sum()) <= 0.01 * so["D"].sum()
+        assert abs(st["objval"] - obj_o) <= 1e-4 * obj_o
+    m.close()
+
+
 def test_tile_kernel_ratings_and_warm_start():
     R = _random_ratings(40000, 150, 0.01, 3)   # 4*(40000+300) > 64 KiB: no LDS kernel
     m = DeviceMatrix.from_scipy(R)
