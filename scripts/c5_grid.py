@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Model-selection grid on a synthetic configuration with R resident in HBM (SURVEY.md §8(d) C5;
+reference loop: src/programs/slim_mselect.c:94-113).  Solves the first N (l1, l2) pairs of
+tests/golden/l12file in file order, each warm-started from the previous model, and prints
+item-columns/s per pair.
+
+  python scripts/c5_grid.py [--workload c5] [--pairs 4] [--scale 1.0] [--columns 0]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c5")
+    ap.add_argument("--pairs", type=int, default=4)
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--columns", type=int, default=0, help="solve only the first N columns (0 = all)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cluster", type=int, default=0, help="tile cluster size (0 = automatic)")
+    args = ap.parse_args()
+    import torch
+    from slim_amd import synth
+    from slim_amd.engine import DeviceMatrix
+
+    dev = torch.device("cuda", 0)
+    nrows, ncols, target = synth.scaled(args.workload, args.scale) if args.scale != 1 \
+        else synth.CONFIGS[args.workload]
+    rowptr, rowind, _ = synth.generate_csr(nrows, ncols, target, seed=args.seed, device=dev)
+    torch.cuda.synchronize()
+    mat = DeviceMatrix.from_device_ptrs(nrows, ncols, rowptr.data_ptr(), rowind.data_ptr(), 0,
+                                        keepalive=(rowptr, rowind), device=0)
+    pairs = [tuple(map(float, l.split())) for l in open(os.path.join(ROOT, "tests", "golden", "l12file"))
+             if l.strip()][:args.pairs]
+    ce = args.columns or mat.ncols
+    prev = None
+    out = []
+    t_all = time.time()
+    for l1, l2 in pairs:
+        t0 = time.time()
+        h, st = mat.learn(imodel=prev, return_handle=True, l1r=l1, l2r=l2, optTol=1e-7, niters=10000,
+                          seed=args.seed, col_begin=0, col_end=ce,
+                          **({"cluster": args.cluster} if args.cluster else {}))
+        dt = time.time() - t0
+        if prev is not None:
+            mat._lib.SLIM_FreeModel(C.byref(C.c_void_p(prev)))
+        prev = h
+        cs = mat.column_stats()
+        rec = {"l1": l1, "l2": l2, "columns": ce, "wall_s": round(dt, 2),
+               "kernel_s": round(st["kernel_ms"] * 1e-3, 2), "columns_per_s": round(ce / dt, 1),
+               "alg_GBps": round(st["alg_bytes"] / (st["kernel_ms"] * 1e-3) / 1e9, 1),
+               "nnzW": int(st["nnzW"]), "mean_sweeps": round(float(cs.sweeps[:ce].mean()), 2),
+               "warm": len(out) > 0}
+        out.append(rec)
+        print(json.dumps(rec), flush=True)
+    print(json.dumps({"workload": args.workload, "nrows": nrows, "ncols": ncols, "nnz": int(rowind.numel()),
+                      "pairs": len(out), "total_s": round(time.time() - t_all, 1)}))
+
+
+if __name__ == "__main__":
+    main()
