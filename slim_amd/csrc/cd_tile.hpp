@@ -127,7 +127,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
   const int32_t* __restrict__ ci = A.colind;
   const float* __restrict__ cv = A.colval;
 
-  const int nrows = A.nrows, ncols = A.ncols;
+  const int ncols = A.ncols;
   const float l1 = S.l1, l2 = S.l2;
 
   // sum over the cluster of a per-problem value (identical in every lane serving q);
@@ -321,7 +321,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 #pragma unroll
           for (int c = 0; c < P / 4; ++c) {
             const float4 f = row[c];
-            any |= tile_active(f.x) | tile_active(f.y) | tile_active(f.z) | tile_active(f.w);
+            any = any || tile_active(f.x) || tile_active(f.y) || tile_active(f.z) || tile_active(f.w);
           }
         }
         const uint64_t m = __ballot(any);

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <numeric>
 #include <string>
 
@@ -431,6 +432,11 @@ slimgpu_matrix_t* matrix_from_host(int32_t nrows, const ssize_t* rowptr, const i
     if (status) *status = status_of(e);
     destroy(m);
     return nullptr;
+  } catch (const std::bad_alloc&) {
+    set_error("SLIMGPU_MatrixFromHost: out of host memory");
+    if (status) *status = SLIM_ERROR_MEMORY;
+    destroy(m);
+    return nullptr;
   }
 }
 
@@ -475,6 +481,11 @@ slimgpu_matrix_t* matrix_from_device(int32_t nrows, int32_t ncols, const int64_t
   } catch (const HipError& e) {
     report(e, "SLIMGPU_MatrixFromDevice");
     if (status) *status = status_of(e);
+    destroy(m);
+    return nullptr;
+  } catch (const std::bad_alloc&) {
+    set_error("SLIMGPU_MatrixFromDevice: out of host memory");
+    if (status) *status = SLIM_ERROR_MEMORY;
     destroy(m);
     return nullptr;
   }
@@ -786,9 +797,16 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     A.cnorm = m->d_cnorm;
     A.csq = m->d_csq;
 
-    hipEvent_t ev0, ev1;
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
+    struct EventPair {  // released on every exit path
+      hipEvent_t a = nullptr, b = nullptr;
+      ~EventPair() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+      }
+    } events;
+    HIP_TRY(hipEventCreate(&events.a));
+    HIP_TRY(hipEventCreate(&events.b));
+    const hipEvent_t ev0 = events.a, ev1 = events.b;
 
     std::vector<int32_t> h_cnt((size_t)ncols, 0);
     std::vector<int64_t> h_off((size_t)ncols, 0);
@@ -947,8 +965,6 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       if (h_misc[1] == 2) {
         set_error("SLIMGPU_Learn: a tile cluster timed out waiting for a member workgroup "
                   "(were all workgroups resident?)");
-        HIP_TRY(hipEventDestroy(ev0));
-        HIP_TRY(hipEventDestroy(ev1));
         return fail(SLIM_ERROR);
       }
       unsigned long long cursor;
@@ -980,8 +996,6 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       pending.swap(again);
       if (!pending.empty()) arena_cap = std::max<int64_t>(arena_cap, need + 1024);
     }
-    HIP_TRY(hipEventDestroy(ev0));
-    HIP_TRY(hipEventDestroy(ev1));
     if (!pending.empty()) {
       set_error("SLIMGPU_Learn: output arena overflow persisted");
       return fail(SLIM_ERROR_MEMORY);
@@ -1057,6 +1071,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
   } catch (const HipError& e) {
     report(e, "SLIMGPU_Learn");
     return fail(status_of(e));
+  } catch (const std::bad_alloc&) {
+    set_error("SLIMGPU_Learn: out of host memory");
+    return fail(SLIM_ERROR_MEMORY);
   }
 }
 

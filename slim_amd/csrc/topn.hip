@@ -19,6 +19,8 @@
 // The score/discovery vectors (12 bytes per item) live in a per-wavefront HBM slab.
 #include <hip/hip_runtime.h>
 
+#include <new>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -275,6 +277,9 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
     set_error(std::string("SLIMGPU_Predict: HIP error '") + hipGetErrorString(e.code) + "' in " +
               e.where);
     return e.code == hipErrorOutOfMemory ? SLIM_ERROR_MEMORY : SLIM_ERROR;
+  } catch (const std::bad_alloc&) {
+    set_error("SLIMGPU_Predict: out of host memory");
+    return SLIM_ERROR_MEMORY;
   }
 }
 
