@@ -894,6 +894,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       const int launch_waves =
           use_tile ? std::max(1, std::min((npend + tileP - 1) / tileP, nclusters)) * clusterK
                    : std::max(1, std::min(npend, nwaves));
+      // the heavy phase needs at least one whole big cluster in the launch
+      if (S.nheavy > 0 && launch_waves < clusterHi) S.nheavy = 0;
       HIP_TRY(hipEventRecord(ev0, stream));
       hipLaunchKernelGGL(fn, dim3(launch_waves), dim3(use_tile ? 64 * tileNW : 64),
                          use_lds ? lds_need : 0, stream, A, S);
