@@ -171,12 +171,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "fixture tests/golden/ml100k-train.csr" if args.workload == "ml100k" else "synthetic",
             "config": {
                 "workload": "%s (%s), nnz %d, %s values, CD l1r=1 l2r=1 optTol=1e-7 "
                             "niters=10000; %d item columns per step per GPU"
-                            % (args.workload, name, nnz, "ratings 1-5" if rowval is not None
-                               else "binary", batch),
+                            % (args.workload, name, nnz,
+                               "stored (all 1.0)" if args.workload == "ml100k" else
+                               "ratings 1-5" if rowval is not None else "binary", batch),
                 "scale": args.scale, "columns_per_step_per_gpu": batch,
                 "parallelism": "columns block-partitioned over %d GPU(s), R replicated" % world,
                 "kernel": {0: "auto", 1: "wave-lds", 2: "wave-hbm", 3: "tile32", 4: "tile16"}.get(st["kernel"], st["kernel"]),

@@ -750,7 +750,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       d_slab = ws_get<float>(m->ws_slab, vec_floats * (size_t)nwaves);
     }
 
-    int64_t arena_cap = std::max<int64_t>(1 << 20, 2 * m->nnz);
+    // output arena: a column of W holds at most ncols - 1 entries and, on the large
+    // configurations, ~2.7K (C4, both densities) to ~4K (C5); columns that do not fit are
+    // solved again with a larger arena (below), so the size is only a matter of cost
+    int64_t arena_cap = std::max<int64_t>(1 << 20, (int64_t)nwork * std::min<int64_t>(ncols, 8192));
     const char* env_cap = std::getenv("SLIM_GPU_ARENA");
     if (env_cap) arena_cap = std::max<int64_t>(1, std::atoll(env_cap));
 
