@@ -99,6 +99,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
   __shared__ int s_grp, s_nunion;
   __shared__ float s_tot[2][P];
   __shared__ int s_abort;
+  __shared__ long long s_G[P];  // Gram work counter per problem (reported with the column)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -234,12 +235,11 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     float* aty = K > 1 ? aty_sh : x;
 
     // -- y scatter + Gram column: wavefront w serves problems w, w+16 (estimate.c:406-421)
-    int64_t Gw[PPW];
 #pragma unroll
     for (int pp = 0; pp < PPW; ++pp) {
       const int pq = wave + pp * NW;
       const int witem = s_item[pq];
-      Gw[pp] = 0;
+      int64_t Gw = 0;
       if (witem >= 0) {
         // this member's users of the column
         const int64_t cs = uni(csplit[(int64_t)witem * (K + 1) + mk]);
@@ -256,7 +256,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           for (int k = 0; k < cnt; ++k) {
             const int64_t rs = lane_bcast(rs_l, k), re = lane_bcast(re_l, k);
             const float v = lane_bcast(v_l, k);
-            Gw[pp] += re - rs;
+            Gw += re - rs;
             for (int64_t e = rs + lane; e < re; e += 64) {
               const float rv = HAS_VAL ? A.rowval[e] : 1.0f;
               atomicAdd(&aty[(int64_t)A.rowind[e] * P + pq], v * rv);
@@ -270,9 +270,10 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
             gsum += A.rowptr[u + 1] - A.rowptr[u];
           }
           for (int off = 32; off > 0; off >>= 1) gsum += __shfl_xor(gsum, off);
-          Gw[pp] = gsum;
+          Gw = gsum;
         }
       }
+      if (lane == 0) s_G[pq] = Gw;
     }
     cluster_barrier();
 
@@ -638,7 +639,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         S.st_na[witem] = s_na[pq];
         S.st_sweeps[witem] = niters;
         S.st_conv[witem] = conv;
-        S.st_G[witem] = Gw[pp];
+        S.st_G[witem] = s_G[pq];
         S.st_D[witem] = Dw;
         S.st_U[witem] = Uw;
         S.st_err[witem] = err;

@@ -617,6 +617,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     // 256 tiles); with many tiles throughput matters and two small workgroups win (150 vs
     // ~141 col/s at 512 tiles).
     int tileNW = (nwork + tileP - 1) / tileP >= 2 * m->num_cus ? 8 : 16;
+    // (four 4-wavefront workgroups per CU were measured too: no gain, even on columns of ~900 nnz)
     if (const char* e = std::getenv("SLIM_GPU_TILE_NW")) tileNW = std::atoi(e) == 16 ? 16 : 8;
     if (use_tile) {
       const bool prof = trace_level >= 2;
