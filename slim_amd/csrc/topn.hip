@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -180,6 +181,288 @@ __global__ __launch_bounds__(64) void topn_kernel(const TopNArgs T) {
   }
 }
 
+// ---- second kernel: score chunks in LDS -------------------------------------------------
+//
+// topn_kernel keeps the 12-byte-per-item score/discovery vectors of a user in HBM, so every
+// multiply-add costs ~4 random sector requests: measured on a C4-shaped model (100K items,
+// 2700 entries per row, histories of ~890 items) it is bound by the request rate at
+// 14e9 adds/s = 5.8K users/s -- slower than the host scorer on a 128-core box.
+//
+// Here a workgroup of 8 wavefronts serves one user and the ITEMS are cut into chunks of CW ids
+// whose score/discovery arrays live in LDS (12 bytes x CW per wavefront).  Wavefront w owns
+// chunks w, w+8, ...; for each of its chunks it walks the user's history in order and, for
+// history item i, only the entries of row i of W whose ids fall into the chunk -- rows are
+// sorted, and wsplit[i][c] (built once per call) is where chunk c starts in row i.  Every
+// candidate still receives its additions in history order, products and sums rounded
+// separately, and the first touch still records (history index, position in the row), so the
+// result is bit-identical to topn_kernel and to the host.  HBM sees each W entry once per
+// user, in coalesced segments; everything else is LDS.
+//   * the (start, length, rating) of up to 64 history items are fetched lane-parallel, then
+//     consumed one item at a time through v_readlane; the segment loads run kT2Depth items
+//     ahead of the LDS updates;
+//   * selection: a wavefront keeps its N best in REGISTERS (lane t = rank t); a candidate that
+//     beats the current N-th is inserted with one ballot + one lane shift; the 8 lists are
+//     merged through LDS by wavefront 0.
+constexpr int kT2Waves = 8;       // default workgroup: 8 wavefronts x 1536-id chunks
+constexpr int kT2Depth = 4;
+constexpr int kT2MaxN = 32;
+constexpr int kT2MaxCW = 1536;
+
+struct TopN2Args {
+  int32_t nusers, nitems_rows, ncols, nrcmds;
+  int32_t cw, nchunks;
+  const int64_t* wptr;
+  const int32_t* wind;
+  const float* wval;
+  const uint32_t* wsplit;  // [nitems_rows][nchunks + 1]: offset in row i of the first id >= c * cw
+  const int64_t* hptr;
+  const int32_t* hind;
+  const float* hval;
+  int32_t* out_ids;
+  float* out_scores;
+  int32_t* out_cnt;
+  int32_t* queue;
+};
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1);
+  const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// rows of W sorted by id?  (one wavefront per row; flag set when an inversion is found)
+__global__ void k_rows_sorted(int32_t nrows, const int64_t* __restrict__ ptr,
+                              const int32_t* __restrict__ ind, int32_t* __restrict__ unsorted) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    const int64_t s = ptr[r], e = ptr[r + 1];
+    bool bad = false;
+    for (int64_t j = s + 1 + lane; j < e; j += 64) bad |= ind[j - 1] >= ind[j];
+    if (bad) atomicExch(unsorted, 1);
+  }
+}
+
+// wsplit[r][c] = number of ids of row r below c * cw (binary search; rows are sorted)
+__global__ void k_row_split(int32_t nrows, int32_t nchunks, int32_t cw,
+                            const int64_t* __restrict__ ptr, const int32_t* __restrict__ ind,
+                            uint32_t* __restrict__ split) {
+  const int64_t total = (int64_t)nrows * (nchunks + 1);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t r = (int32_t)(t / (nchunks + 1)), c = (int32_t)(t % (nchunks + 1));
+    const int64_t s = ptr[r], e = ptr[r + 1];
+    const int64_t bound = (int64_t)c * cw;
+    int64_t lo = s, hi = e;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)ind[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    split[t] = (uint32_t)(lo - s);
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void topn_chunk_kernel(const TopN2Args T) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = kT2Depth;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = T.nrcmds, CW = T.cw;
+  unsigned long long* disc = reinterpret_cast<unsigned long long*>(smem) + (size_t)wave * CW;
+  float* score = reinterpret_cast<float*>(smem + (size_t)NW * CW * 8) + (size_t)wave * CW;
+  char* marea = smem + (size_t)NW * CW * 12;
+  float* m_s = reinterpret_cast<float*>(marea);
+  unsigned long long* m_d = reinterpret_cast<unsigned long long*>(marea + NW * kT2MaxN * 4);
+  int* m_id = reinterpret_cast<int*>(marea + NW * kT2MaxN * 12);
+  int* m_cnt = reinterpret_cast<int*>(marea + NW * kT2MaxN * 16);
+  __shared__ int s_user;
+
+  for (;;) {
+    if (tid == 0) s_user = atomicAdd(T.queue, 1);
+    __syncthreads();
+    const int u = __builtin_amdgcn_readfirstlane(s_user);
+    if (u >= T.nusers) break;
+    const int64_t h0 = uni64(T.hptr[u]), h1 = uni64(T.hptr[u + 1]);
+
+    // this wavefront's N best so far: lane t holds rank t
+    float ls = 0.0f;
+    unsigned long long ld = kUntouched;
+    int lid = -1;
+    int count = 0;
+    float worst_s = 0.0f;
+    unsigned long long worst_d = 0;
+    auto insert = [&](const float cs, const unsigned long long cd, const int cid) {
+      const bool ahead = lane < count && better(ls, ld, cs, cd);
+      const int p = __popcll(__ballot(ahead));  // sorted list: the entries ahead are ranks 0..p-1
+      const float us = __shfl_up(ls, 1);
+      const unsigned long long ud = shfl_up64(ld);
+      const int uid = __shfl_up(lid, 1);
+      if (lane > p && lane < N) {
+        ls = us;
+        ld = ud;
+        lid = uid;
+      }
+      if (lane == p) {
+        ls = cs;
+        ld = cd;
+        lid = cid;
+      }
+      if (count < N) ++count;
+      if (count == N) {
+        worst_s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ls), N - 1));
+        worst_d = readlane64(ld, N - 1);
+      }
+    };
+    auto offer = [&](const float cs, const unsigned long long cd, const int cid) {
+      if (count < N || better(cs, cd, worst_s, worst_d)) insert(cs, cd, cid);
+    };
+
+    for (int c = wave; c < T.nchunks; c += NW) {
+      const int base = c * CW;
+      const int width = (T.ncols - base) < CW ? (T.ncols - base) : CW;
+      for (int k = lane; k < width; k += 64) disc[k] = kUntouched;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      for (int64_t h = h0 + lane; h < h1; h += 64) {  // history items are never recommended
+        const int i = T.hind[h];
+        if (i >= base && i < base + width) disc[i - base] = kExcluded;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+
+      auto update = [&](const int idx, const unsigned long long key, const float prod) {
+        const unsigned long long d = disc[idx];
+        if (d != kExcluded) {
+#pragma clang fp contract(off)
+          float acc = 0.0f;
+          if (d == kUntouched)
+            disc[idx] = key;
+          else
+            acc = score[idx];
+          score[idx] = acc + prod;
+        }
+      };
+
+      for (int64_t hb = h0; hb < h1; hb += 64) {
+        const int nb = (h1 - hb) < 64 ? (int)(h1 - hb) : 64;
+        // lane l: where history item hb + l meets this chunk
+        int64_t my_s = 0;
+        int my_len = 0;
+        uint32_t my_p0 = 0;
+        float my_r = 1.0f;
+        if (lane < nb) {
+          const int i = T.hind[hb + lane];
+          if (T.hval) my_r = T.hval[hb + lane];
+          if (i >= 0 && i < T.nitems_rows) {
+            const uint32_t* sp = T.wsplit + (int64_t)i * (T.nchunks + 1) + c;
+            my_p0 = sp[0];
+            my_len = (int)(sp[1] - my_p0);
+            my_s = T.wptr[i] + my_p0;
+          }
+        }
+        int qk[D];
+        float qv[D];
+        auto fetch = [&](const int l, int& k, float& v) {
+          const int64_t s = (int64_t)readlane64((unsigned long long)my_s, l);
+          const int len = __builtin_amdgcn_readlane(my_len, l);
+          k = -1;
+          v = 0.0f;
+          if (lane < len) {
+            k = T.wind[s + lane];
+            v = T.wval[s + lane];
+          }
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          qk[d] = -1;
+          qv[d] = 0.0f;
+          if (d < nb) fetch(d, qk[d], qv[d]);
+        }
+        for (int lb = 0; lb < nb; lb += D) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            const int l = lb + d;
+            if (l < nb) {
+              const int k = qk[d];
+              const float v = qv[d];
+              if (l + D < nb) fetch(l + D, qk[d], qv[d]);
+              const float rating = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_r), l));
+              const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)my_p0, l);
+              const int len = __builtin_amdgcn_readlane(my_len, l);
+              const unsigned long long hkey = (unsigned long long)(uint32_t)(hb - h0 + l) << 32;
+              if (k >= 0) {
+#pragma clang fp contract(off)
+                const float prod = rating * v;
+                update(k - base, hkey | (unsigned long long)(p0 + (uint32_t)lane), prod);
+              }
+              if (len > 64) {  // a segment longer than one wavefront step (dense rows)
+                const int64_t s = (int64_t)readlane64((unsigned long long)my_s, l);
+                for (int t = 64 + lane; t < len; t += 64) {
+#pragma clang fp contract(off)
+                  const float prod = rating * T.wval[s + t];
+                  update(T.wind[s + t] - base, hkey | (unsigned long long)(p0 + (uint32_t)t), prod);
+                }
+              }
+            }
+          }
+        }
+      }
+
+      // candidates of this chunk against the wavefront's N best
+      for (int kb = 0; kb < width; kb += 64) {
+        const int k = kb + lane;
+        unsigned long long d = kUntouched;
+        float sc = 0.0f;
+        if (k < width) {
+          d = disc[k];
+          sc = score[k];
+        }
+        bool want = d < kExcluded;
+        if (want && count == N) want = better(sc, d, worst_s, worst_d);
+        unsigned long long mask = __ballot(want);
+        while (mask) {
+          const int l = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const float cs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), l));
+          const unsigned long long cd = readlane64(d, l);
+          offer(cs, cd, base + kb + l);
+        }
+      }
+    }
+
+    // merge the wavefronts' lists (wavefront 0), write the user's row
+    if (lane < kT2MaxN) {
+      m_s[wave * kT2MaxN + lane] = ls;
+      m_d[wave * kT2MaxN + lane] = ld;
+      m_id[wave * kT2MaxN + lane] = lid;
+    }
+    if (lane == 0) m_cnt[wave] = count;
+    __syncthreads();
+    if (wave == 0) {
+      for (int w = 1; w < NW; ++w) {
+        const int cw_ = __builtin_amdgcn_readfirstlane(m_cnt[w]);
+        for (int t = 0; t < cw_; ++t) {
+          const float cs = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m_s[w * kT2MaxN + t])));
+          const unsigned long long cd = (unsigned long long)uni64((int64_t)m_d[w * kT2MaxN + t]);
+          const int cid = __builtin_amdgcn_readfirstlane(m_id[w * kT2MaxN + t]);
+          offer(cs, cd, cid);
+        }
+      }
+      if (lane < count) {
+        T.out_ids[(int64_t)u * N + lane] = lid;
+        T.out_scores[(int64_t)u * N + lane] = ls;
+      }
+      if (lane == 0) T.out_cnt[u] = count;
+    }
+    __syncthreads();
+  }
+}
+
 struct HipFail {
   hipError_t code;
   const char* where;
@@ -220,16 +503,11 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
     int dev = 0;
     TOPN_TRY(hipGetDevice(&dev));
     TOPN_TRY(hipGetDeviceProperties(&prop, dev));
-    const size_t lds = (size_t)nrcmds * 64 * (sizeof(float) + sizeof(unsigned long long) + sizeof(int));
-    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (128 * 1024) / lds));
-    const int nwaves = std::max(1, std::min<int>(nusers, prop.multiProcessorCount * per_cu));
-
     DevBuf<int64_t> d_wptr((size_t)W->nrows + 1), d_hptr((size_t)nusers + 1);
     DevBuf<int32_t> d_wind((size_t)wnnz), d_hind((size_t)hnnz);
     DevBuf<float> d_wval((size_t)wnnz), d_hval(hist->rowval ? (size_t)hnnz : 1);
-    DevBuf<float> d_score((size_t)nwaves * ncols), d_oscore((size_t)nusers * nrcmds);
-    DevBuf<unsigned long long> d_disc((size_t)nwaves * ncols);
-    DevBuf<int32_t> d_oid((size_t)nusers * nrcmds), d_ocnt((size_t)nusers), d_queue(1);
+    DevBuf<float> d_oscore((size_t)nusers * nrcmds);
+    DevBuf<int32_t> d_oid((size_t)nusers * nrcmds), d_ocnt((size_t)nusers), d_queue(2);
     TOPN_TRY(hipMemcpy(d_wptr.p, W->rowptr, sizeof(int64_t) * ((size_t)W->nrows + 1), hipMemcpyHostToDevice));
     TOPN_TRY(hipMemcpy(d_hptr.p, hist->rowptr, sizeof(int64_t) * ((size_t)nusers + 1), hipMemcpyHostToDevice));
     if (wnnz) {
@@ -241,24 +519,90 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
       if (hist->rowval)
         TOPN_TRY(hipMemcpy(d_hval.p, hist->rowval, sizeof(float) * (size_t)hnnz, hipMemcpyHostToDevice));
     }
-    TOPN_TRY(hipMemset(d_queue.p, 0, sizeof(int32_t)));
+    TOPN_TRY(hipMemset(d_queue.p, 0, 2 * sizeof(int32_t)));
     TOPN_TRY(hipMemset(d_ocnt.p, 0, sizeof(int32_t) * (size_t)nusers));
 
-    TopNArgs T;
-    T.nusers = nusers;
-    T.nitems_rows = W->nrows;
-    T.ncols = ncols;
-    T.nrcmds = nrcmds;
-    T.wptr = d_wptr.p; T.wind = d_wind.p; T.wval = d_wval.p;
-    T.hptr = d_hptr.p; T.hind = d_hind.p; T.hval = hist->rowval ? d_hval.p : nullptr;
-    T.score = d_score.p; T.disc = d_disc.p;
-    T.out_ids = d_oid.p; T.out_scores = d_oscore.p; T.out_cnt = d_ocnt.p; T.queue = d_queue.p;
-    if (lds > 64 * 1024)
-      TOPN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(topn_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(topn_kernel, dim3(nwaves), dim3(64), lds, 0, T);
-    TOPN_TRY(hipGetLastError());
-    TOPN_TRY(hipDeviceSynchronize());
+    // kernel choice: score chunks in LDS (lists of up to 32, rows of W sorted by id), else the
+    // one-wavefront-per-user kernel with its vectors in HBM.  SLIM_TOPN_KERNEL=wave|chunk and
+    // SLIM_TOPN_CW=<chunk width> override (tests).
+    const char* kenv = std::getenv("SLIM_TOPN_KERNEL");
+    bool chunked = nrcmds <= kT2MaxN && !(kenv && std::strcmp(kenv, "wave") == 0);
+    if (chunked) {
+      int32_t unsorted = 0;
+      if (wnnz > 0) {
+        hipLaunchKernelGGL(k_rows_sorted, dim3(std::max(1, std::min(W->nrows / 4 + 1, prop.multiProcessorCount * 8))),
+                           dim3(256), 0, 0, W->nrows, d_wptr.p, d_wind.p, d_queue.p + 1);
+        TOPN_TRY(hipGetLastError());
+        TOPN_TRY(hipMemcpy(&unsorted, d_queue.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+      }
+      if (unsorted) chunked = false;
+    }
+    int t2w = kT2Waves;
+    if (const char* e = std::getenv("SLIM_TOPN_WAVES")) t2w = std::atoi(e) == 16 ? 16 : 8;
+    const int max_cw = kT2MaxCW * kT2Waves / t2w;  // same LDS footprint either way
+    int cw = std::max(64, std::min(max_cw, ((ncols + t2w - 1) / t2w + 63) / 64 * 64));
+    if (const char* e = std::getenv("SLIM_TOPN_CW")) {
+      const int v = std::atoi(e);
+      if (v >= 64 && v <= max_cw && v % 64 == 0) cw = v;
+    }
+    const int nchunks = (ncols + cw - 1) / cw;
+    if (chunked && (size_t)W->nrows * ((size_t)nchunks + 1) * sizeof(uint32_t) > (size_t(2) << 30))
+      chunked = false;
+    if (kenv && std::strcmp(kenv, "chunk") == 0 && !chunked) {
+      set_error("SLIMGPU_Predict: SLIM_TOPN_KERNEL=chunk needs nrcmds <= 32 and model rows sorted by id");
+      return SLIM_ERROR_INPUT;
+    }
+
+    if (chunked) {
+      DevBuf<uint32_t> d_split((size_t)std::max(W->nrows, 1) * ((size_t)nchunks + 1));
+      if (W->nrows > 0) {
+        const int64_t total = (int64_t)W->nrows * (nchunks + 1);
+        hipLaunchKernelGGL(k_row_split, dim3((unsigned)std::min<int64_t>((total + 255) / 256, prop.multiProcessorCount * 16)),
+                           dim3(256), 0, 0, W->nrows, nchunks, cw, d_wptr.p, d_wind.p, d_split.p);
+        TOPN_TRY(hipGetLastError());
+      }
+      TopN2Args T;
+      T.nusers = nusers;
+      T.nitems_rows = W->nrows;
+      T.ncols = ncols;
+      T.nrcmds = nrcmds;
+      T.cw = cw;
+      T.nchunks = nchunks;
+      T.wptr = d_wptr.p; T.wind = d_wind.p; T.wval = d_wval.p; T.wsplit = d_split.p;
+      T.hptr = d_hptr.p; T.hind = d_hind.p; T.hval = hist->rowval ? d_hval.p : nullptr;
+      T.out_ids = d_oid.p; T.out_scores = d_oscore.p; T.out_cnt = d_ocnt.p; T.queue = d_queue.p;
+      const size_t lds = (size_t)t2w * cw * 12 + (size_t)t2w * kT2MaxN * 16 + t2w * sizeof(int);
+      auto kfn = t2w == 16 ? topn_chunk_kernel<16> : topn_chunk_kernel<8>;
+      if (lds > 64 * 1024)
+        TOPN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(32 / t2w, (160 * 1024) / (lds + 64)));
+      const int nwg = std::max(1, std::min<int>(nusers, prop.multiProcessorCount * per_cu));
+      hipLaunchKernelGGL(kfn, dim3(nwg), dim3(64 * t2w), lds, 0, T);
+      TOPN_TRY(hipGetLastError());
+      TOPN_TRY(hipDeviceSynchronize());
+    } else {
+      const size_t lds = (size_t)nrcmds * 64 * (sizeof(float) + sizeof(unsigned long long) + sizeof(int));
+      int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (128 * 1024) / lds));
+      const int nwaves = std::max(1, std::min<int>(nusers, prop.multiProcessorCount * per_cu));
+      DevBuf<float> d_score((size_t)nwaves * ncols);
+      DevBuf<unsigned long long> d_disc((size_t)nwaves * ncols);
+      TopNArgs T;
+      T.nusers = nusers;
+      T.nitems_rows = W->nrows;
+      T.ncols = ncols;
+      T.nrcmds = nrcmds;
+      T.wptr = d_wptr.p; T.wind = d_wind.p; T.wval = d_wval.p;
+      T.hptr = d_hptr.p; T.hind = d_hind.p; T.hval = hist->rowval ? d_hval.p : nullptr;
+      T.score = d_score.p; T.disc = d_disc.p;
+      T.out_ids = d_oid.p; T.out_scores = d_oscore.p; T.out_cnt = d_ocnt.p; T.queue = d_queue.p;
+      if (lds > 64 * 1024)
+        TOPN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(topn_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(topn_kernel, dim3(nwaves), dim3(64), lds, 0, T);
+      TOPN_TRY(hipGetLastError());
+      TOPN_TRY(hipDeviceSynchronize());
+    }
 
     std::vector<int32_t> h_id((size_t)nusers * nrcmds), h_cnt((size_t)nusers);
     std::vector<float> h_sc((size_t)nusers * nrcmds);

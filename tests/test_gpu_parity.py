@@ -419,11 +419,21 @@ def test_edge_cases():
 
 
 # ---- top-N prediction on the GPU ---------------------------------------------
-def _predict_both(lib, hm, hr, nusers, n):
+TOPN_MODES = [{}, {"SLIM_TOPN_KERNEL": "wave"}, {"SLIM_TOPN_KERNEL": "chunk"},
+              {"SLIM_TOPN_KERNEL": "chunk", "SLIM_TOPN_CW": "64"}]
+
+
+def _predict_both(lib, hm, hr, nusers, n, env=None):
+    """GPU scorer (optionally with the kernel pinned through the environment) and host scorer."""
     import os
     out_g = np.full(nusers * n, -1, np.int32)
     sc_g = np.zeros(nusers * n, np.float32)
-    assert lib.SLIMGPU_Predict(n, hm, hr, out_g, sc_g) == SLIM_OK
+    os.environ.update(env or {})
+    try:
+        assert lib.SLIMGPU_Predict(n, hm, hr, out_g, sc_g) == SLIM_OK, _lib.last_error()
+    finally:
+        for k in (env or {}):
+            del os.environ[k]
     out_c = np.full(nusers * n, -1, np.int32)
     sc_c = np.zeros(nusers * n, np.float32)
     os.environ["SLIM_PREDICT"] = "cpu"
@@ -453,9 +463,12 @@ def test_gpu_topn_is_bit_identical_to_host(ml100k, ml_dev, n):
     R, T = ml100k
     hm, _ = ml_dev.learn(seed=1, return_handle=True)
     hr = _wrap(lib, R)
-    ids_g, sc_g, ids_c, sc_c = _predict_both(lib, hm, hr, R.shape[0], n)
-    assert np.array_equal(ids_g, ids_c)
-    assert np.array_equal(sc_g, sc_c)
+    for env in TOPN_MODES:
+        if n > 32 and env.get("SLIM_TOPN_KERNEL") == "chunk":
+            continue   # the LDS-chunk kernel keeps lists of up to 32 in registers
+        ids_g, sc_g, ids_c, sc_c = _predict_both(lib, hm, hr, R.shape[0], n, env)
+        assert np.array_equal(ids_g, ids_c), env
+        assert np.array_equal(sc_g, sc_c), env
     # and both are what the oracle's GetRecommendations gives
     W = model_to_scipy(lib, hm, free=False)
     o_ids, o_sc = O.predict(W, R, n)
@@ -476,8 +489,9 @@ def test_gpu_topn_ratings_short_lists_and_ties(automotive):
     m = DeviceMatrix.from_scipy(R)
     hm, _ = m.learn(l1r=20.0, l2r=1.0, niters=100, return_handle=True)  # sparse model: short lists
     hr = _wrap(lib, R)
-    ids_g, sc_g, ids_c, sc_c = _predict_both(lib, hm, hr, R.shape[0], 20)
-    assert np.array_equal(ids_g, ids_c) and np.array_equal(sc_g, sc_c)
+    for env in TOPN_MODES:
+        ids_g, sc_g, ids_c, sc_c = _predict_both(lib, hm, hr, R.shape[0], 20, env)
+        assert np.array_equal(ids_g, ids_c) and np.array_equal(sc_g, sc_c), env
     assert (ids_c == -1).any()              # some users have fewer than 20 candidates
     # a model with many exactly tied scores: W = all ones on a band
     n = 300
@@ -488,13 +502,58 @@ def test_gpu_topn_ratings_short_lists_and_ties(automotive):
                   dtype=np.float32)
     H.data[:] = 1.0
     hh = _wrap(lib, sp.csr_matrix((H.data, H.indices, H.indptr), shape=(200, n)))
-    ids_g, sc_g, ids_c, sc_c = _predict_both(lib, ht, hh, 200, 7)
-    assert np.array_equal(ids_g, ids_c) and np.array_equal(sc_g, sc_c)
+    for env in TOPN_MODES:
+        ids_g, sc_g, ids_c, sc_c = _predict_both(lib, ht, hh, 200, 7, env)
+        assert np.array_equal(ids_g, ids_c) and np.array_equal(sc_g, sc_c), env
     for h in (hr, hh):
         lib.Py_csr_free(h)
     for h in (C.c_void_p(hm), ht):
         lib.SLIM_FreeModel(C.byref(h))
     m.close()
+
+
+def test_gpu_topn_chunk_kernel_wide_model():
+    """The LDS-chunk scorer on a model wide enough for several chunks per wavefront, with dense
+    rows (chunk segments longer than one wavefront step), repeated and out-of-range history
+    items, rated histories, empty histories: ids and float scores equal the host scorer's."""
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+    n = 20000
+    W = sp.random(n, n, density=0.004, format="lil", random_state=rng, dtype=np.float32)
+    for r in (5, 77, 4000):                       # dense rows: ~6000 entries
+        cols = np.sort(rng.choice(n, 6000, replace=False))
+        W.rows[r] = list(cols)
+        W.data[r] = list(rng.random(6000).astype(np.float32))
+    W = sp.csr_matrix(W)
+    W.data = (W.data * 0.1).astype(np.float32)
+    W.sort_indices()
+    from slim_amd.engine import _scipy_to_model_handle
+    hW = _scipy_to_model_handle(lib, W)
+    nu = 600
+    H = sp.random(nu, n, density=0.003, format="csr", random_state=rng, dtype=np.float32)
+    H.data = rng.integers(1, 6, H.nnz).astype(np.float32)
+    H = sp.lil_matrix(H)
+    H.rows[0], H.data[0] = [], []                               # no history
+    H.rows[1], H.data[1] = [5, 77, 4000], [1.0, 2.0, 3.0]       # only the dense rows
+    H = sp.csr_matrix(H)
+    H.sort_indices()
+    # user 3: its first item twice; user 4: an item id beyond the model (both legal inputs)
+    rows = [list(zip(H.indices[H.indptr[u]:H.indptr[u + 1]], H.data[H.indptr[u]:H.indptr[u + 1]]))
+            for u in range(nu)]
+    rows[3] = rows[3] + rows[3][:1]
+    rows[4] = rows[4] + [(n + 5, 2.0)]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])])
+    H = sp.csr_matrix((np.array([v for r in rows for _, v in r], np.float32),
+                       np.array([i for r in rows for i, _ in r], np.int32), indptr), shape=(nu, n + 6))
+    hH = _wrap(lib, H)
+    for env in ({"SLIM_TOPN_KERNEL": "chunk"}, {"SLIM_TOPN_KERNEL": "chunk", "SLIM_TOPN_CW": "640"},
+                {"SLIM_TOPN_KERNEL": "wave"}):
+        for N in (10, 32):
+            ids_g, sc_g, ids_c, sc_c = _predict_both(lib, hW, hH, nu, N, env)
+            assert np.array_equal(ids_g, ids_c) and np.array_equal(sc_g, sc_c), (env, N)
+    assert (ids_c[0] == -1).all() and (ids_c[2] >= 0).all()
+    lib.Py_csr_free(hH)
+    lib.SLIM_FreeModel(C.byref(hW))
 
 
 # ---- SURVEY 8(f) #3: fSLIM (nnbrs > 0) -----------------------------------------------------------
