@@ -211,6 +211,7 @@ constexpr int kT2MaxCW = 1536;
 struct TopN2Args {
   int32_t nusers, nitems_rows, ncols, nrcmds;
   int32_t cw, nchunks;
+  int32_t pos_bits;  // discovery key = history index << pos_bits | position in the row
   const int64_t* wptr;
   const int32_t* wind;
   const float* wval;
@@ -233,6 +234,17 @@ __device__ __forceinline__ unsigned long long shfl_up64(unsigned long long v) {
   const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1);
   const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1);
   return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned long long readlane_key(unsigned long long v, int l) { return readlane64(v, l); }
+__device__ __forceinline__ uint32_t readlane_key(uint32_t v, int l) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ unsigned long long shfl_up_key(unsigned long long v) { return shfl_up64(v); }
+__device__ __forceinline__ uint32_t shfl_up_key(uint32_t v) { return (uint32_t)__shfl_up((int)v, 1); }
+template <typename KeyT>
+__device__ __forceinline__ bool better(float sa, KeyT da, float sb, KeyT db) {
+  return sa > sb || (sa == sb && da < db);
 }
 
 // rows of W sorted by id?  (one wavefront per row; flag set when an inversion is found)
@@ -268,18 +280,22 @@ __global__ void k_row_split(int32_t nrows, int32_t nchunks, int32_t cw,
   }
 }
 
-template <int NW>
+// KeyT: discovery key (history index << pos_bits | position in the model row).  32 bits when
+// the longest history and the longest model row allow it (8 bytes of LDS per item: chunks of
+// 2304 ids), else 64.
+template <int NW, typename KeyT>
 __global__ __launch_bounds__(64 * NW) void topn_chunk_kernel(const TopN2Args T) {
+  constexpr KeyT kUnt = ~KeyT(0), kExc = ~KeyT(0) - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = kT2Depth;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = T.nrcmds, CW = T.cw;
-  unsigned long long* disc = reinterpret_cast<unsigned long long*>(smem) + (size_t)wave * CW;
-  float* score = reinterpret_cast<float*>(smem + (size_t)NW * CW * 8) + (size_t)wave * CW;
-  char* marea = smem + (size_t)NW * CW * 12;
+  KeyT* disc = reinterpret_cast<KeyT*>(smem) + (size_t)wave * CW;
+  float* score = reinterpret_cast<float*>(smem + (size_t)NW * CW * sizeof(KeyT)) + (size_t)wave * CW;
+  char* marea = smem + (size_t)NW * CW * (sizeof(KeyT) + 4);
   float* m_s = reinterpret_cast<float*>(marea);
-  unsigned long long* m_d = reinterpret_cast<unsigned long long*>(marea + NW * kT2MaxN * 4);
+  KeyT* m_d = reinterpret_cast<KeyT*>(marea + NW * kT2MaxN * 4);
   int* m_id = reinterpret_cast<int*>(marea + NW * kT2MaxN * 12);
   int* m_cnt = reinterpret_cast<int*>(marea + NW * kT2MaxN * 16);
   __shared__ int s_user;
@@ -293,16 +309,16 @@ __global__ __launch_bounds__(64 * NW) void topn_chunk_kernel(const TopN2Args T) 
 
     // this wavefront's N best so far: lane t holds rank t
     float ls = 0.0f;
-    unsigned long long ld = kUntouched;
+    KeyT ld = kUnt;
     int lid = -1;
     int count = 0;
     float worst_s = 0.0f;
-    unsigned long long worst_d = 0;
-    auto insert = [&](const float cs, const unsigned long long cd, const int cid) {
+    KeyT worst_d = 0;
+    auto insert = [&](const float cs, const KeyT cd, const int cid) {
       const bool ahead = lane < count && better(ls, ld, cs, cd);
       const int p = __popcll(__ballot(ahead));  // sorted list: the entries ahead are ranks 0..p-1
       const float us = __shfl_up(ls, 1);
-      const unsigned long long ud = shfl_up64(ld);
+      const KeyT ud = shfl_up_key(ld);
       const int uid = __shfl_up(lid, 1);
       if (lane > p && lane < N) {
         ls = us;
@@ -317,30 +333,30 @@ __global__ __launch_bounds__(64 * NW) void topn_chunk_kernel(const TopN2Args T) 
       if (count < N) ++count;
       if (count == N) {
         worst_s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ls), N - 1));
-        worst_d = readlane64(ld, N - 1);
+        worst_d = readlane_key(ld, N - 1);
       }
     };
-    auto offer = [&](const float cs, const unsigned long long cd, const int cid) {
+    auto offer = [&](const float cs, const KeyT cd, const int cid) {
       if (count < N || better(cs, cd, worst_s, worst_d)) insert(cs, cd, cid);
     };
 
     for (int c = wave; c < T.nchunks; c += NW) {
       const int base = c * CW;
       const int width = (T.ncols - base) < CW ? (T.ncols - base) : CW;
-      for (int k = lane; k < width; k += 64) disc[k] = kUntouched;
+      for (int k = lane; k < width; k += 64) disc[k] = kUnt;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       for (int64_t h = h0 + lane; h < h1; h += 64) {  // history items are never recommended
         const int i = T.hind[h];
-        if (i >= base && i < base + width) disc[i - base] = kExcluded;
+        if (i >= base && i < base + width) disc[i - base] = kExc;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 
-      auto update = [&](const int idx, const unsigned long long key, const float prod) {
-        const unsigned long long d = disc[idx];
-        if (d != kExcluded) {
+      auto update = [&](const int idx, const KeyT key, const float prod) {
+        const KeyT d = disc[idx];
+        if (d != kExc) {
 #pragma clang fp contract(off)
           float acc = 0.0f;
-          if (d == kUntouched)
+          if (d == kUnt)
             disc[idx] = key;
           else
             acc = score[idx];
@@ -394,18 +410,18 @@ __global__ __launch_bounds__(64 * NW) void topn_chunk_kernel(const TopN2Args T) 
               const float rating = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_r), l));
               const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)my_p0, l);
               const int len = __builtin_amdgcn_readlane(my_len, l);
-              const unsigned long long hkey = (unsigned long long)(uint32_t)(hb - h0 + l) << 32;
+              const KeyT hkey = (KeyT)(uint32_t)(hb - h0 + l) << T.pos_bits;
               if (k >= 0) {
 #pragma clang fp contract(off)
                 const float prod = rating * v;
-                update(k - base, hkey | (unsigned long long)(p0 + (uint32_t)lane), prod);
+                update(k - base, hkey | (KeyT)(p0 + (uint32_t)lane), prod);
               }
               if (len > 64) {  // a segment longer than one wavefront step (dense rows)
                 const int64_t s = (int64_t)readlane64((unsigned long long)my_s, l);
                 for (int t = 64 + lane; t < len; t += 64) {
 #pragma clang fp contract(off)
                   const float prod = rating * T.wval[s + t];
-                  update(T.wind[s + t] - base, hkey | (unsigned long long)(p0 + (uint32_t)t), prod);
+                  update(T.wind[s + t] - base, hkey | (KeyT)(p0 + (uint32_t)t), prod);
                 }
               }
             }
@@ -416,20 +432,20 @@ __global__ __launch_bounds__(64 * NW) void topn_chunk_kernel(const TopN2Args T) 
       // candidates of this chunk against the wavefront's N best
       for (int kb = 0; kb < width; kb += 64) {
         const int k = kb + lane;
-        unsigned long long d = kUntouched;
+        KeyT d = kUnt;
         float sc = 0.0f;
         if (k < width) {
           d = disc[k];
           sc = score[k];
         }
-        bool want = d < kExcluded;
+        bool want = d < kExc;
         if (want && count == N) want = better(sc, d, worst_s, worst_d);
         unsigned long long mask = __ballot(want);
         while (mask) {
           const int l = __builtin_ctzll(mask);
           mask &= mask - 1;
           const float cs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), l));
-          const unsigned long long cd = readlane64(d, l);
+          const KeyT cd = readlane_key(d, l);
           offer(cs, cd, base + kb + l);
         }
       }
@@ -448,7 +464,7 @@ __global__ __launch_bounds__(64 * NW) void topn_chunk_kernel(const TopN2Args T) 
         const int cw_ = __builtin_amdgcn_readfirstlane(m_cnt[w]);
         for (int t = 0; t < cw_; ++t) {
           const float cs = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m_s[w * kT2MaxN + t])));
-          const unsigned long long cd = (unsigned long long)uni64((int64_t)m_d[w * kT2MaxN + t]);
+          const KeyT cd = readlane_key(m_d[w * kT2MaxN + t], 0);
           const int cid = __builtin_amdgcn_readfirstlane(m_id[w * kT2MaxN + t]);
           offer(cs, cd, cid);
         }
@@ -539,7 +555,16 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
     }
     int t2w = kT2Waves;
     if (const char* e = std::getenv("SLIM_TOPN_WAVES")) t2w = std::atoi(e) == 16 ? 16 : 8;
-    const int max_cw = kT2MaxCW * kT2Waves / t2w;  // same LDS footprint either way
+    // discovery keys: 32 bits when (longest history, longest model row) fit, else 64
+    int64_t max_hist = 0, max_row = 0;
+    for (int32_t u = 0; u < nusers; ++u) max_hist = std::max<int64_t>(max_hist, hist->rowptr[u + 1] - hist->rowptr[u]);
+    for (int32_t r = 0; r < W->nrows; ++r) max_row = std::max<int64_t>(max_row, W->rowptr[r + 1] - W->rowptr[r]);
+    auto bits_for = [](int64_t v) { int b = 0; while ((int64_t(1) << b) <= v) ++b; return b; };
+    bool key32 = bits_for(max_row) + bits_for(max_hist) <= 31;
+    if (const char* e = std::getenv("SLIM_TOPN_KEY")) key32 = key32 && std::atoi(e) != 64;
+    const int pos_bits = key32 ? bits_for(max_row) : 32;
+    const int item_bytes = key32 ? 8 : 12;
+    const int max_cw = kT2MaxCW * 12 * kT2Waves / (item_bytes * t2w) / 64 * 64;  // same LDS footprint
     int cw = std::max(64, std::min(max_cw, ((ncols + t2w - 1) / t2w + 63) / 64 * 64));
     if (const char* e = std::getenv("SLIM_TOPN_CW")) {
       const int v = std::atoi(e);
@@ -568,11 +593,14 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
       T.nrcmds = nrcmds;
       T.cw = cw;
       T.nchunks = nchunks;
+      T.pos_bits = pos_bits;
       T.wptr = d_wptr.p; T.wind = d_wind.p; T.wval = d_wval.p; T.wsplit = d_split.p;
       T.hptr = d_hptr.p; T.hind = d_hind.p; T.hval = hist->rowval ? d_hval.p : nullptr;
       T.out_ids = d_oid.p; T.out_scores = d_oscore.p; T.out_cnt = d_ocnt.p; T.queue = d_queue.p;
-      const size_t lds = (size_t)t2w * cw * 12 + (size_t)t2w * kT2MaxN * 16 + t2w * sizeof(int);
-      auto kfn = t2w == 16 ? topn_chunk_kernel<16> : topn_chunk_kernel<8>;
+      const size_t lds = (size_t)t2w * cw * item_bytes + (size_t)t2w * kT2MaxN * 16 + t2w * sizeof(int);
+      auto kfn = key32 ? (t2w == 16 ? topn_chunk_kernel<16, uint32_t> : topn_chunk_kernel<8, uint32_t>)
+                       : (t2w == 16 ? topn_chunk_kernel<16, unsigned long long>
+                                    : topn_chunk_kernel<8, unsigned long long>);
       if (lds > 64 * 1024)
         TOPN_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

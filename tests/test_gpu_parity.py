@@ -420,7 +420,8 @@ def test_edge_cases():
 
 # ---- top-N prediction on the GPU ---------------------------------------------
 TOPN_MODES = [{}, {"SLIM_TOPN_KERNEL": "wave"}, {"SLIM_TOPN_KERNEL": "chunk"},
-              {"SLIM_TOPN_KERNEL": "chunk", "SLIM_TOPN_CW": "64"}]
+              {"SLIM_TOPN_KERNEL": "chunk", "SLIM_TOPN_CW": "64"},
+              {"SLIM_TOPN_KERNEL": "chunk", "SLIM_TOPN_KEY": "64"}]   # 64-bit discovery keys
 
 
 def _predict_both(lib, hm, hr, nusers, n, env=None):
@@ -547,6 +548,7 @@ def test_gpu_topn_chunk_kernel_wide_model():
                        np.array([i for r in rows for i, _ in r], np.int32), indptr), shape=(nu, n + 6))
     hH = _wrap(lib, H)
     for env in ({"SLIM_TOPN_KERNEL": "chunk"}, {"SLIM_TOPN_KERNEL": "chunk", "SLIM_TOPN_CW": "640"},
+                {"SLIM_TOPN_KERNEL": "chunk", "SLIM_TOPN_KEY": "64", "SLIM_TOPN_WAVES": "16"},
                 {"SLIM_TOPN_KERNEL": "wave"}):
         for N in (10, 32):
             ids_g, sc_g, ids_c, sc_c = _predict_both(lib, hW, hH, nu, N, env)
