@@ -22,6 +22,7 @@
 #include <new>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -204,13 +205,14 @@ __global__ __launch_bounds__(64) void topn_kernel(const TopNArgs T) {
 //     beats the current N-th is inserted with one ballot + one lane shift; the 8 lists are
 //     merged through LDS by wavefront 0.
 constexpr int kT2Waves = 8;       // default workgroup: 8 wavefronts x 1536-id chunks
-constexpr int kT2Depth = 4;
+constexpr int kT2Depth = 16;
 constexpr int kT2MaxN = 32;
 constexpr int kT2MaxCW = 1536;
 
 struct TopN2Args {
   int32_t nusers, nitems_rows, ncols, nrcmds;
   int32_t cw, nchunks;
+  uint32_t wlast;    // nnz(W) - 1 (0 for an empty model): clamp for the unconditional loads
   int32_t pos_bits;  // discovery key = history index << pos_bits | position in the row
   const int64_t* wptr;
   const int32_t* wind;
@@ -351,23 +353,21 @@ __global__ __launch_bounds__(64 * NW) void topn_chunk_kernel(const TopN2Args T) 
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 
+      // branch-free: both reads issue together; an untouched slot reads garbage as its score and
+      // selects 0; an excluded slot keeps its key and accumulates a score nobody reads
       auto update = [&](const int idx, const KeyT key, const float prod) {
-        const KeyT d = disc[idx];
-        if (d != kExc) {
 #pragma clang fp contract(off)
-          float acc = 0.0f;
-          if (d == kUnt)
-            disc[idx] = key;
-          else
-            acc = score[idx];
-          score[idx] = acc + prod;
-        }
+        const KeyT d = disc[idx];
+        const float old = score[idx];
+        const bool first = d == kUnt;
+        disc[idx] = first ? key : d;
+        score[idx] = (first ? 0.0f : old) + prod;
       };
 
       for (int64_t hb = h0; hb < h1; hb += 64) {
         const int nb = (h1 - hb) < 64 ? (int)(h1 - hb) : 64;
         // lane l: where history item hb + l meets this chunk
-        int64_t my_s = 0;
+        uint32_t my_s = 0;  // element offset of the segment in wind / wval (nnz(W) < 2^31)
         int my_len = 0;
         uint32_t my_p0 = 0;
         float my_r = 1.0f;
@@ -378,51 +378,50 @@ __global__ __launch_bounds__(64 * NW) void topn_chunk_kernel(const TopN2Args T) 
             const uint32_t* sp = T.wsplit + (int64_t)i * (T.nchunks + 1) + c;
             my_p0 = sp[0];
             my_len = (int)(sp[1] - my_p0);
-            my_s = T.wptr[i] + my_p0;
+            my_s = (uint32_t)T.wptr[i] + my_p0;
           }
         }
-        int qk[D];
+        // The segment loads are UNCONDITIONAL instructions (clamped address, predicate applied
+        // when the entry is consumed) and every step issues exactly one fetch: the number of
+        // loads in flight is then the same on every path, so the compiler can wait for the oldest
+        // fetch only (s_waitcnt vmcnt(2*(D-1))).  With loads under `if (lane < len)` it had to
+        // drain the queue at every step, and the kernel ran at one L2 round trip per step
+        // whatever the depth.  Items past the batch have length 0: their steps do nothing.
+        int qk[D], qlen[D];
         float qv[D];
-        auto fetch = [&](const int l, int& k, float& v) {
-          const int64_t s = (int64_t)readlane64((unsigned long long)my_s, l);
-          const int len = __builtin_amdgcn_readlane(my_len, l);
-          k = -1;
-          v = 0.0f;
-          if (lane < len) {
-            k = T.wind[s + lane];
-            v = T.wval[s + lane];
-          }
+        auto fetch = [&](const int l, int& k, float& v, int& len) {
+          const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)my_s, l);
+          len = __builtin_amdgcn_readlane(my_len, l);
+          uint32_t j = s + (uint32_t)lane;
+          j = j < T.wlast ? j : T.wlast;
+          k = T.wind[j];
+          v = T.wval[j];
         };
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-          qk[d] = -1;
-          qv[d] = 0.0f;
-          if (d < nb) fetch(d, qk[d], qv[d]);
-        }
-        for (int lb = 0; lb < nb; lb += D) {
+        for (int d = 0; d < D; ++d) fetch(d, qk[d], qv[d], qlen[d]);
+        const int nbp = (nb + D - 1) / D * D;  // <= 64: lanes past nb hold length 0
+        for (int lb = 0; lb < nbp; lb += D) {
 #pragma unroll
           for (int d = 0; d < D; ++d) {
             const int l = lb + d;
-            if (l < nb) {
-              const int k = qk[d];
-              const float v = qv[d];
-              if (l + D < nb) fetch(l + D, qk[d], qv[d]);
-              const float rating = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_r), l));
-              const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)my_p0, l);
-              const int len = __builtin_amdgcn_readlane(my_len, l);
-              const KeyT hkey = (KeyT)(uint32_t)(hb - h0 + l) << T.pos_bits;
-              if (k >= 0) {
+            const int kraw = qk[d];
+            const float v = qv[d];
+            const int len = qlen[d];
+            fetch((l + D) & 63, qk[d], qv[d], qlen[d]);
+            const float rating = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_r), l));
+            const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)my_p0, l);
+            const KeyT hkey = (KeyT)(uint32_t)(hb - h0 + l) << T.pos_bits;
+            if (lane < len) {
 #pragma clang fp contract(off)
-                const float prod = rating * v;
-                update(k - base, hkey | (KeyT)(p0 + (uint32_t)lane), prod);
-              }
-              if (len > 64) {  // a segment longer than one wavefront step (dense rows)
-                const int64_t s = (int64_t)readlane64((unsigned long long)my_s, l);
-                for (int t = 64 + lane; t < len; t += 64) {
+              const float prod = rating * v;
+              update(kraw - base, hkey | (KeyT)(p0 + (uint32_t)lane), prod);
+            }
+            if (len > 64) {  // a segment longer than one wavefront step (dense rows)
+              const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)my_s, l);
+              for (uint32_t t = 64 + (uint32_t)lane; t < (uint32_t)len; t += 64) {
 #pragma clang fp contract(off)
-                  const float prod = rating * T.wval[s + t];
-                  update(T.wind[s + t] - base, hkey | (KeyT)(p0 + (uint32_t)t), prod);
-                }
+                const float prod = rating * T.wval[s + t];
+                update(T.wind[s + t] - base, hkey | (KeyT)(p0 + t), prod);
               }
             }
           }
@@ -511,6 +510,7 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
   const int32_t nusers = hist->nrows;
   const int32_t ncols = std::max(W->ncols, 1);
   const int64_t wnnz = W->rowptr[W->nrows], hnnz = hist->rowptr[nusers];
+  const auto t_begin = std::chrono::steady_clock::now();
   try {
     int ndev = 0;
     TOPN_TRY(hipGetDeviceCount(&ndev));
@@ -542,7 +542,8 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
     // one-wavefront-per-user kernel with its vectors in HBM.  SLIM_TOPN_KERNEL=wave|chunk and
     // SLIM_TOPN_CW=<chunk width> override (tests).
     const char* kenv = std::getenv("SLIM_TOPN_KERNEL");
-    bool chunked = nrcmds <= kT2MaxN && !(kenv && std::strcmp(kenv, "wave") == 0);
+    bool chunked = nrcmds <= kT2MaxN && wnnz < (int64_t(1) << 31) &&
+                   !(kenv && std::strcmp(kenv, "wave") == 0);
     if (chunked) {
       int32_t unsorted = 0;
       if (wnnz > 0) {
@@ -594,6 +595,7 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
       T.cw = cw;
       T.nchunks = nchunks;
       T.pos_bits = pos_bits;
+      T.wlast = wnnz > 0 ? (uint32_t)(wnnz - 1) : 0u;
       T.wptr = d_wptr.p; T.wind = d_wind.p; T.wval = d_wval.p; T.wsplit = d_split.p;
       T.hptr = d_hptr.p; T.hind = d_hind.p; T.hval = hist->rowval ? d_hval.p : nullptr;
       T.out_ids = d_oid.p; T.out_scores = d_oscore.p; T.out_cnt = d_ocnt.p; T.queue = d_queue.p;
@@ -606,9 +608,16 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(32 / t2w, (160 * 1024) / (lds + 64)));
       const int nwg = std::max(1, std::min<int>(nusers, prop.multiProcessorCount * per_cu));
+      const auto t_k0 = std::chrono::steady_clock::now();
       hipLaunchKernelGGL(kfn, dim3(nwg), dim3(64 * t2w), lds, 0, T);
       TOPN_TRY(hipGetLastError());
       TOPN_TRY(hipDeviceSynchronize());
+      if (std::getenv("SLIM_GPU_TRACE"))
+        std::fprintf(stderr, "[trace] top-N chunk kernel: %d users, %d workgroups of %d wavefronts, chunks of %d ids, "
+                             "%d-bit keys: %.1f ms (upload + split table before it: %.1f ms)\n",
+                     nusers, nwg, t2w, cw, key32 ? 32 : 64,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_k0).count(),
+                     std::chrono::duration<double, std::milli>(t_k0 - t_begin).count());
     } else {
       const size_t lds = (size_t)nrcmds * 64 * (sizeof(float) + sizeof(unsigned long long) + sizeof(int));
       int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (128 * 1024) / lds));
