@@ -442,14 +442,20 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       }
       load_ids(c0);  // last chunk: kept in registers for the update
       gather();
-      // (sn_v / nn_v are still in flight when the visit starts: made uniform only here)
-      const int64_t sn = HI ? uni(sn_v) : 0, en = HI ? sn + uni(nn_v) : 0;
-      if (HI && S.hi_prefetch && mode == 0 && en > sn) {
-        const int64_t b0 = sn + 64 * wave;
-        const bool ok = b0 + lane < en;
-        pf_id = ok ? ci[b0 + lane] - ubase : 0;
-        pf_v = ok ? (HAS_VAL ? cv[b0 + lane] : 1.0f) : 0.0f;
-        pf_at = sn;
+      // (sn_v / nn_v are still in flight when the visit starts: made uniform only here.)  The
+      // loads are unconditional instructions with a clamped address -- lanes past the slice hold
+      // garbage that load_ids never looks at -- so that exactly one (two with values) load is in
+      // flight behind the gather on every path and the dot below waits for the gather only
+      // (s_waitcnt vmcnt(1|2)); a load under a condition makes the count path-dependent and the
+      // compiler drains the queue instead.
+      if (HI && mode == 0) {
+        const int64_t sn = uni(sn_v);
+        const int nn = uni(nn_v);
+        int64_t jj = sn + 64 * wave + lane;
+        jj = jj < S.nnz_last ? jj : S.nnz_last;
+        pf_id = ci[jj] - ubase;
+        pf_v = HAS_VAL ? cv[jj] : 1.0f;
+        pf_at = (nn > 0 && S.hi_prefetch) ? sn : -1;
       }
       const uint64_t p1 = tick();
 

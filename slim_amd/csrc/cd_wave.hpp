@@ -91,6 +91,7 @@ struct SolveArgs {
   unsigned long long* mailbox_hi;
   float* atyshared_hi;
   int32_t* queue_hi;
+  int64_t nnz_last;              // nnz - 1 (0 for an empty matrix): clamp for unconditional loads
   int32_t hi_prefetch;           // heavy phase: request the next visit's ids early
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;

@@ -869,6 +869,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.atyshared_hi = d_atysh ? d_atysh + (clusterK > 1 ? tile_x * (size_t)nclusters : 0) : nullptr;
       S.queue_hi = d_misc + 4;
       S.hi_prefetch = 1;
+      S.nnz_last = m->nnz > 0 ? m->nnz - 1 : 0;
       if (const char* e = std::getenv("SLIM_GPU_HI_PREFETCH")) S.hi_prefetch = std::atoi(e);
       if (use_tile)
         HIP_TRY(hipMemsetAsync(d_mailbox, 0, sizeof(unsigned long long) * mailbox_words, stream));
