@@ -357,6 +357,16 @@ def test_tile_kernel_heavy_phase_long_slices():
         assert (cs.sweeps == so["sweeps"]).mean() >= 0.98
         assert abs(cs.D.sum() - so["D"].sum()) <= 0.01 * so["D"].sum()
         assert abs(st["objval"] - obj_o) <= 1e-4 * obj_o
+    # warm start through the heavy phase (the fold of the previous coefficients runs in both
+    # cluster geometries): same fixed point and sweep counts as the plain tile kernel
+    first, _ = m.learn(l1r=3.0, l2r=1.0, optTol=1e-13, niters=100000, seed=3, kernel=KERNEL_TILE)
+    ref, _ = m.learn(l1r=1.0, l2r=1.0, optTol=1e-13, niters=100000, seed=3, kernel=KERNEL_TILE,
+                     imodel=first, cluster=1, heavy_tiles=0)
+    ref_sweeps = m.column_stats().sweeps.copy()
+    got, _ = m.learn(l1r=1.0, l2r=1.0, optTol=1e-13, niters=100000, seed=3, kernel=KERNEL_TILE,
+                     imodel=first, cluster=1, heavy_tiles=2, heavy_cluster=4)
+    assert maxdiff(got, ref) <= 2e-6
+    assert (m.column_stats().sweeps == ref_sweeps).mean() >= 0.95
     m.close()
 
 
