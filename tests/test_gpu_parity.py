@@ -626,6 +626,10 @@ def test_output_arena_overflow_is_recovered(ml100k, ml_gpu, monkeypatch):
     W, st = m.learn(seed=1, kernel=KERNEL_TILE)
     assert abs(W.nnz - ml_gpu[0].nnz) <= 60 and maxdiff(W, ml_gpu[0]) <= 3e-3
     assert abs(st["objval"] - ml_gpu[1]["objval"]) <= 1e-4 * st["objval"]
+    # ... also when the first attempt ran a heavy phase (the retry regroups into plain clusters)
+    W, st = m.learn(seed=1, kernel=KERNEL_TILE, cluster=2, heavy_tiles=6, heavy_cluster=8)
+    assert abs(W.nnz - ml_gpu[0].nnz) <= 60 and maxdiff(W, ml_gpu[0]) <= 3e-3
+    assert abs(st["objval"] - ml_gpu[1]["objval"]) <= 1e-4 * st["objval"]
     m.close()
 
 
@@ -642,9 +646,10 @@ def test_tile_clusters_kkt_on_synthetic_c4_shape():
     R = sp.csr_matrix((val.numpy(), ind.numpy(), ptr.numpy()), shape=(nr, nc))
     m = DeviceMatrix.from_scipy(R, binary=True)
     b, e = 1000, 1000 + 256
-    for cl in (0, 4):  # automatic and explicit cluster sizes
+    # automatic and explicit cluster sizes, and a heavy phase (2 tiles in clusters of 16 first)
+    for geom in ({}, {"cluster": 4}, {"cluster": 4, "heavy_tiles": 2, "heavy_cluster": 16}):
         W, st = m.learn(l1r=1.0, l2r=1.0, optTol=1e-12, niters=100000, col_begin=b, col_end=e,
-                        **({"cluster": cl} if cl else {}))
+                        **geom)
         assert st["kernel"] == KERNEL_TILE and W.nnz > 0
         X = sp.csc_matrix(W)[:, b:e]
         assert X.data.min() > 0 and np.asarray(X[np.arange(b, e), np.arange(e - b)]).max() == 0
