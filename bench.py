@@ -194,6 +194,8 @@ def main():
                 "sweeps": acc["sweeps"],
             },
         }
+        if world == 1:
+            out["parity"] = ml100k_parity(local_rank)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, rowptr, rowind, rowval, nrows, ncols,
                                                first_b, batch, opts, W)
@@ -201,6 +203,53 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def ml100k_parity(device):
+    """The second half of BASELINE.json's metric: HR@10 / ARHR on ml100k against the reference's
+    0.3191 / 0.1504 (slim_predict.c:181-236 semantics).  Product path only:
+    engine solve (cd, l1 = l2 = 1), GPU top-N scorer, hit counting in numpy."""
+    import ctypes as C
+    import numpy as np
+    from slim_amd import _lib
+    from slim_amd.engine import DeviceMatrix
+    from slim_amd.io import read_csr_text
+    lib = _lib.load()
+    R = read_csr_text(os.path.join(ROOT, "tests", "golden", "ml100k-train.csr"))
+    T = read_csr_text(os.path.join(ROOT, "tests", "golden", "ml100k-test.csr"))
+    m = DeviceMatrix.from_scipy(R, device=device)
+    t0 = time.perf_counter()
+    h, st = m.learn(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=1, return_handle=True)
+    t_learn = time.perf_counter() - t0
+    hr_ = C.c_void_p()
+    val = np.ascontiguousarray(R.data, np.float32)
+    lib.Py_csr_wrapper(R.shape[0], np.ascontiguousarray(R.indptr, np.intp),
+                       np.ascontiguousarray(R.indices, np.int32), val.ctypes.data_as(C.c_void_p),
+                       C.byref(hr_))
+    n = 10
+    ids = np.full(R.shape[0] * n, -1, np.int32)
+    sc = np.zeros(R.shape[0] * n, np.float32)
+    rc = lib.SLIMGPU_Predict(n, h, hr_, ids, sc)
+    ids = ids.reshape(-1, n)
+    hits = arhr = 0.0
+    nvalid = 0
+    for u in range(T.shape[0]):
+        test = T.indices[T.indptr[u]:T.indptr[u + 1]]
+        if test.size == 0:
+            continue
+        nvalid += 1
+        got = [r for r in range(n) if ids[u, r] >= 0 and ids[u, r] in test]
+        hits += len(got) / float(test.size)                       # pyapi.c:309-366
+        arhr += sum(1.0 / (1 + r) for r in got) / sum(1.0 / (1 + z) for z in range(test.size))
+    lib.Py_csr_free(hr_)
+    hh = C.c_void_p(h)
+    lib.SLIM_FreeModel(C.byref(hh))
+    m.close()
+    hr10, arhr = hits / max(nvalid, 1), arhr / max(nvalid, 1)
+    return {"dataset": "ml100k (tests/golden), cd l1r=1 l2r=1", "hr10": round(hr10, 4), "arhr": round(arhr, 4),
+            "reference_hr10": 0.3191, "reference_arhr": 0.1504, "users": nvalid,
+            "match": bool(rc == 1 and "%.4f" % hr10 == "0.3191" and "%.4f" % arhr == "0.1504"),
+            "learn_ms": round(1e3 * t_learn, 2), "W_nnz": int(st["nnzW"])}
 
 
 def pmc_traffic(args, batch, kernel, binary):
