@@ -113,4 +113,16 @@ def learn_sharded(mat, group=None, **opts):
     b, e = blocks[rank]
     W_local, stats = mat.learn(col_begin=b, col_end=e, **opts)
     W = gather_model(W_local, group) if world > 1 else W_local
+    # the reductions of EstimateModelCD (estimate.c:371-373: error, objval) and the solve
+    # counters, summed over the ranks; per-rank values stay under their own names
+    stats = dict(stats)
+    keys = [k for k in ("objval", "error", "nnzW", "G", "D", "U", "sweeps", "ncols_solved") if k in stats]
+    if world > 1 and keys:
+        import torch
+        t = torch.tensor([float(stats[k]) for k in keys], dtype=torch.float64, device=_default_device())
+        dist.all_reduce(t, group=group)
+        totals = t.tolist()
+    else:
+        totals = [float(stats[k]) for k in keys]
+    stats["totals"] = dict(zip(keys, totals))
     return W, stats, (b, e)

@@ -51,9 +51,9 @@ class _OracleMatrix(object):
 
     def learn(self, col_begin=0, col_end=None, seed=1, **kw):
         cols = np.arange(col_begin, col_end, dtype=np.int32)
-        W = self.O.learn_cd(self.R, order=self.O.ORDER_PERM, seed=seed, aty=self.O.ATY_GRAM,
-                            cols=cols)
-        return W, {"ncols_solved": len(cols)}
+        W, st, err, obj = self.O.learn_cd(self.R, order=self.O.ORDER_PERM, seed=seed,
+                                          aty=self.O.ATY_GRAM, cols=cols, return_stats=True)
+        return W, {"ncols_solved": len(cols), "objval": obj, "error": err, "nnzW": W.nnz}
 
 
 def _worker(rank, world, port, out_dir):
@@ -80,6 +80,8 @@ def _worker(rank, world, port, out_dir):
         W, stats, (b, e) = learn_sharded(_OracleMatrix(R), seed=3)
         sp.save_npz(os.path.join(out_dir, "w%d.npz" % rank), sp.csc_matrix(W))
         np.save(os.path.join(out_dir, "b%d.npy" % rank), np.array([b, e, stats["ncols_solved"]]))
+        np.save(os.path.join(out_dir, "t%d.npy" % rank),
+                np.array([stats["totals"][k] for k in ("objval", "error", "nnzW", "ncols_solved")]))
         # binary matrices broadcast without a value array
         p2, i2, v2 = broadcast_csr(ptr if rank == 0 else None, ind if rank == 0 else None, None)
         assert v2 is None and torch.equal(p2, ptr) and torch.equal(i2, ind)
@@ -104,7 +106,7 @@ def test_sharded_learn_two_ranks_gloo(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     R = read_csr_text(os.path.join(GOLDEN, "ml100k-train.csr"))[:, :400].tocsr()
-    want = O.learn_cd(R, order=O.ORDER_PERM, seed=3, aty=O.ATY_GRAM)
+    want, _, err, obj = O.learn_cd(R, order=O.ORDER_PERM, seed=3, aty=O.ATY_GRAM, return_stats=True)
     w0 = sp.load_npz(str(tmp_path / "w0.npz"))
     w1 = sp.load_npz(str(tmp_path / "w1.npz"))
     assert abs(w0 - w1).nnz == 0                  # every rank holds the full model
@@ -112,3 +114,8 @@ def test_sharded_learn_two_ranks_gloo(tmp_path):
     b0, b1 = np.load(str(tmp_path / "b0.npy")), np.load(str(tmp_path / "b1.npy"))
     assert b0[0] == 0 and b0[1] == b1[0] and b1[1] == want.shape[1]
     assert b0[2] + b1[2] == want.shape[1] and min(b0[2], b1[2]) > 0
+    # the objective / error reductions (estimate.c:371-373) are summed over the ranks
+    t0, t1 = np.load(str(tmp_path / "t0.npy")), np.load(str(tmp_path / "t1.npy"))
+    assert np.array_equal(t0, t1)
+    assert abs(t0[0] - obj) <= 1e-9 * obj and abs(t0[1] - err) <= 1e-9 * err
+    assert t0[2] == want.nnz and t0[3] == want.shape[1]
