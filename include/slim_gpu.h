@@ -156,6 +156,14 @@ int32_t SLIMGPU_MatrixColumnCost(const slimgpu_matrix_t *mat, int64_t *cost);
 slim_t *SLIMGPU_Learn(slimgpu_matrix_t *mat, int32_t *ioptions,
                       double *doptions, slim_t *imodel, int32_t *r_status);
 
+/* Same for an explicit set of item columns (distinct ids, any order) instead of the range in
+ * option slots 11/12: the unit of work of a shard whose columns are not contiguous, and of
+ * the parity tests that solve one tile of a full-size matrix.  Columns not listed come back
+ * empty.  The engine's work list is the given list stably sorted by descending cost. */
+slim_t *SLIMGPU_LearnColumns(slimgpu_matrix_t *mat, int32_t ncolumns,
+                             const int32_t *columns, int32_t *ioptions,
+                             double *doptions, slim_t *imodel, int32_t *r_status);
+
 /* Py_SLIM_Predict on the GPU (one wavefront per user; lists and scores are bit-identical
  * to the host scorer, ties included).  1 <= nrcmds <= 128.  Fails without a device. */
 int32_t SLIMGPU_Predict(int32_t nrcmds, slim_t *slimhandle, slim_t *trnhandle,

@@ -86,6 +86,8 @@ _SIGNATURES = {
     "SLIMGPU_MatrixColumnCost": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "SLIMGPU_Learn": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_int32)]),
+    "SLIMGPU_LearnColumns": (C.c_void_p, [C.c_void_p, C.c_int32, i32_1d, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.POINTER(C.c_int32)]),
     "SLIMGPU_Predict": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, i32_1d, f32_1d]),
     "SLIMGPU_LastStats": (C.c_int32, [C.POINTER(Stats)]),
     "SLIMGPU_LastColumnStats": (C.c_int32, [C.c_int32] + [C.c_void_p] * 6),

@@ -168,7 +168,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           if (wall_clock64() - t0 > 1000000000ull) {  // 10 s at 100 MHz: give up, loudly
             aborted = true;
             s_abort = 1;
-            atomicExch(S.overflow, 2);
+            atomicMax(S.overflow, 2);  // (max: an arena overflow, 1, never downgrades it)
           }
         }
 #pragma unroll
@@ -572,6 +572,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     }
 
     const uint64_t t_sweeps = wall_clock64();
+    if (s_abort) return false;  // aborted launch: this tile's columns are not reported
     // -- 1/2 ||r||^2 and the objective, per problem (estimate.c:477-489)
     {
       float e2 = 0.0f, reg = 0.0f;
@@ -639,7 +640,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       const int conv = lane_bcast(conv_q, pq);
       const int64_t Dw = lane_bcast(D_q, pq), Uw = lane_bcast(U_q, pq);
       if (lane == 0) {
-        if (!fits) atomicExch(S.overflow, 1);
+        if (!fits) atomicMax(S.overflow, 1);
         S.out_cnt[witem] = fits ? nz : -nz - 1;
         S.out_off[witem] = (int64_t)off;
         S.st_na[witem] = s_na[pq];

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64) void cd_wave_kernel(const DevMatrix A, const So
       }
     }
     if (lane == 0) {
-      if (!fits) atomicExch(S.overflow, 1);
+      if (!fits) atomicMax(S.overflow, 1);
       S.out_cnt[iC] = fits ? nz : -nz - 1;
       S.out_off[iC] = (int64_t)off;
       S.st_na[iC] = na;

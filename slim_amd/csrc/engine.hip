@@ -20,7 +20,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
-#include "cd_tile.hpp"
+#include "tile_inst.hpp"
 #include "cd_wave.hpp"
 #include "engine.hpp"
 #include "host_csr.hpp"
@@ -71,6 +71,10 @@ thread_local ColumnStats g_colstats;
 struct HipError {
   hipError_t code;
   std::string where;
+};
+
+struct InputError {  // malformed caller data: SLIM_ERROR_INPUT
+  std::string msg;
 };
 
 #define HIP_TRY(expr)                                                              \
@@ -125,17 +129,29 @@ __global__ void k_max_index(const int32_t* __restrict__ ind, int64_t n, int32_t*
   if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
+// Input checks done while staging (the reference trusts its caller; a GPU kernel fed a
+// malformed CSR corrupts memory instead of crashing cleanly).  Bits of the flag word:
+constexpr int kBadRowptr = 1;   // rowptr not non-decreasing / not ending at nnz
+constexpr int kBadColumn = 2;   // item id outside [0, ncols)
+constexpr int kDupEntry = 4;    // the same (user, item) pair twice
+
 // key = item id, payload = (user id << 32 | value bits); one wavefront per row
-__global__ void k_pack_rows(int32_t nrows, const int64_t* __restrict__ rowptr,
+__global__ void k_pack_rows(int32_t nrows, int32_t ncols, int64_t nnz,
+                            const int64_t* __restrict__ rowptr,
                             const int32_t* __restrict__ rowind,
                             const float* __restrict__ rowval, uint32_t* __restrict__ keys,
-                            uint64_t* __restrict__ payload) {
+                            uint64_t* __restrict__ payload, int32_t* __restrict__ flags) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t u = wave; u < nrows; u += nwaves) {
-    const int64_t s = rowptr[u], e = rowptr[u + 1];
+    int64_t s = rowptr[u], e = rowptr[u + 1];
+    if (s < 0 || e < s || e > nnz || (u == 0 && s != 0)) {
+      if (lane == 0) atomicOr(flags, kBadRowptr);
+      continue;  // never index with a bad offset
+    }
     for (int64_t k = s + lane; k < e; k += 64) {
+      if ((uint32_t)rowind[k] >= (uint32_t)ncols) atomicOr(flags, kBadColumn);
       keys[k] = (uint32_t)rowind[k];
       const uint32_t bits = rowval ? __float_as_uint(rowval[k]) : 0x3F800000u;
       payload[k] = ((uint64_t)(uint32_t)u << 32) | bits;
@@ -151,6 +167,15 @@ __global__ void k_unpack_cols(int64_t nnz, const uint64_t* __restrict__ payload,
     colind[k] = (int32_t)(p >> 32);
     if (colval) colval[k] = __uint_as_float((uint32_t)p);
   }
+}
+
+// after the stable sort a repeated (user, item) pair is two adjacent equal entries of a column
+__global__ void k_check_dups(int64_t nnz, const uint32_t* __restrict__ keys,
+                             const uint64_t* __restrict__ payload, int32_t* __restrict__ flags) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; k < nnz;
+       k += (int64_t)gridDim.x * blockDim.x)
+    if (keys[k] == keys[k - 1] && (payload[k] >> 32) == (payload[k - 1] >> 32))
+      atomicOr(flags, kDupEntry);
 }
 
 // colptr from the sorted keys: entry k opens every column in (key[k-1], key[k]]
@@ -259,9 +284,29 @@ void build_column_view(slimgpu_matrix* m) {
     uint64_t* pay_in = dev_alloc<uint64_t>((size_t)nnz);
     uint64_t* pay_out = dev_alloc<uint64_t>((size_t)nnz);
     const int cap = m->num_cus * 16;
+    int32_t* d_flags = dev_alloc<int32_t>(1);
+    HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_pack_rows, dim3(grid_for((int64_t)m->nrows * 64, 256, cap)), dim3(256), 0,
-                       st, m->nrows, m->d_rowptr, m->d_rowind, m->d_rowval, keys_in, pay_in);
+                       st, m->nrows, m->ncols, nnz, m->d_rowptr, m->d_rowind, m->d_rowval, keys_in,
+                       pay_in, d_flags);
     HIP_TRY(hipGetLastError());
+    int32_t h_flags = 0;
+    HIP_TRY(hipMemcpyAsync(&h_flags, d_flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    auto release_tmp = [&]() {
+      (void)hipFree(d_flags);
+      (void)hipFree(keys_in);
+      (void)hipFree(keys_out);
+      (void)hipFree(pay_in);
+      (void)hipFree(pay_out);
+      (void)hipFree(d_cost);
+    };
+    if (h_flags) {  // checked before the sort: its bit count assumes ids < ncols
+      release_tmp();
+      throw InputError{h_flags & kBadRowptr
+                           ? "rowptr is not a non-decreasing offset array ending at nnz"
+                           : "item id outside [0, ncols)"};
+    }
     unsigned bits = 1;
     while ((1ull << bits) < (unsigned long long)m->ncols) ++bits;
     size_t tmp_bytes = 0;
@@ -271,18 +316,29 @@ void build_column_view(slimgpu_matrix* m) {
     HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
     HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, pay_in, pay_out,
                                       (size_t)nnz, 0u, bits, st));
+    hipLaunchKernelGGL(k_check_dups, dim3(grid_for(nnz, 256, cap)), dim3(256), 0, st, nnz,
+                       keys_out, pay_out, d_flags);
+    HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_unpack_cols, dim3(grid_for(nnz, 256, cap)), dim3(256), 0, st, nnz,
                        pay_out, m->d_colind, m->d_colval);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_col_offsets, dim3(grid_for(nnz + 1, 256, cap)), dim3(256), 0, st, nnz,
                        m->ncols, keys_out, m->d_colptr);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&h_flags, d_flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipFree(tmp));
     HIP_TRY(hipFree(keys_in));
     HIP_TRY(hipFree(keys_out));
     HIP_TRY(hipFree(pay_in));
     HIP_TRY(hipFree(pay_out));
+    HIP_TRY(hipFree(d_flags));
+    if (h_flags & kDupEntry) {
+      // the reference walks duplicates as separate entries (norm from v1^2 + v2^2, dots from
+      // v1 + v2): not a well-defined problem, and two lanes updating one residual race here
+      (void)hipFree(d_cost);
+      throw InputError{"duplicate (user, item) entries in the rating matrix"};
+    }
   } else {
     HIP_TRY(hipMemsetAsync(m->d_colptr, 0, sizeof(int64_t) * ((size_t)m->ncols + 1), st));
   }
@@ -343,7 +399,7 @@ void destroy(slimgpu_matrix* m) {
   (void)hipFree(m->d_colval);
   (void)hipFree(m->d_cnorm);
   (void)hipFree(m->d_csq);
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < 6; ++k) {
     (void)hipFree(m->d_ubounds[k]);
     (void)hipFree(m->d_csplit[k]);
   }
@@ -432,6 +488,11 @@ slimgpu_matrix_t* matrix_from_host(int32_t nrows, const ssize_t* rowptr, const i
     if (status) *status = status_of(e);
     destroy(m);
     return nullptr;
+  } catch (const InputError& e) {
+    set_error(std::string("SLIMGPU_MatrixFromHost: ") + e.msg);
+    if (status) *status = SLIM_ERROR_INPUT;
+    destroy(m);
+    return nullptr;
   } catch (const std::bad_alloc&) {
     set_error("SLIMGPU_MatrixFromHost: out of host memory");
     if (status) *status = SLIM_ERROR_MEMORY;
@@ -481,6 +542,11 @@ slimgpu_matrix_t* matrix_from_device(int32_t nrows, int32_t ncols, const int64_t
   } catch (const HipError& e) {
     report(e, "SLIMGPU_MatrixFromDevice");
     if (status) *status = status_of(e);
+    destroy(m);
+    return nullptr;
+  } catch (const InputError& e) {
+    set_error(std::string("SLIMGPU_MatrixFromDevice: ") + e.msg);
+    if (status) *status = SLIM_ERROR_INPUT;
     destroy(m);
     return nullptr;
   } catch (const std::bad_alloc&) {
@@ -537,8 +603,6 @@ int32_t matrix_get_column_view(const slimgpu_matrix_t* m, int64_t* colptr, int32
 
 namespace {
 
-using KernelFn = void (*)(const DevMatrix, const SolveArgs);
-
 KernelFn pick_kernel(bool lds, bool has_val) {
   if (lds) return has_val ? cd_wave_kernel<true, true> : cd_wave_kernel<true, false>;
   return has_val ? cd_wave_kernel<false, true> : cd_wave_kernel<false, false>;
@@ -549,7 +613,7 @@ int round_up(int v, int q) { return (v + q - 1) / q * q; }
 }  // namespace
 
 slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
-                     int32_t* status) {
+                     int32_t* status, const int32_t* columns, int32_t ncolumns) {
   const double t_begin = now_ms();
   slimgpu_stats_t st;
   std::memset(&st, 0, sizeof(st));
@@ -565,7 +629,18 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
   int32_t cb = std::max(0, opt.col_begin);
   int32_t ce = opt.col_end < 0 ? ncols : std::min(opt.col_end, ncols);
   if (cb > ce) cb = ce;
-  const int32_t nwork = ce - cb;
+  int32_t nwork = ce - cb;
+  if (columns) {  // an explicit set of item columns instead of a range
+    std::vector<char> seen((size_t)ncols, 0);
+    for (int32_t k = 0; k < ncolumns; ++k) {
+      if (columns[k] < 0 || columns[k] >= ncols || seen[(size_t)columns[k]]) {
+        set_error("SLIMGPU_LearnColumns: column ids must be distinct and inside [0, ncols)");
+        return fail(SLIM_ERROR_INPUT);
+      }
+      seen[(size_t)columns[k]] = 1;
+    }
+    nwork = ncolumns;
+  }
 
   try {
     HIP_TRY(hipSetDevice(m->device));
@@ -573,7 +648,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
 
     // work list: most expensive columns first (longest-processing-time order)
     std::vector<int32_t> order((size_t)nwork);
-    std::iota(order.begin(), order.end(), cb);
+    if (columns)
+      std::copy(columns, columns + nwork, order.begin());
+    else
+      std::iota(order.begin(), order.end(), cb);
+    const std::vector<int32_t> requested = order;
     std::stable_sort(order.begin(), order.end(),
                      [&](int32_t a, int32_t b) { return m->h_cost[a] > m->h_cost[b]; });
 
@@ -622,14 +701,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     if (use_tile) {
       const bool prof = trace_level >= 2;
       const bool val = !m->binary;
-#define SLIM_TILE_PICK(PP, NWW)                                                              \
-  (val ? (prof ? cd_tile_kernel<PP, true, true, NWW> : cd_tile_kernel<PP, true, false, NWW>)  \
-       : (prof ? cd_tile_kernel<PP, false, true, NWW> : cd_tile_kernel<PP, false, false, NWW>))
       if (tileP == 32)
-        fn = tileNW == 16 ? SLIM_TILE_PICK(32, 16) : SLIM_TILE_PICK(32, 8);
+        fn = tileNW == 16 ? tile_kernel_p32_nw16(val, prof) : tile_kernel_p32_nw8(val, prof);
       else
-        fn = tileNW == 16 ? SLIM_TILE_PICK(16, 16) : SLIM_TILE_PICK(16, 8);
-#undef SLIM_TILE_PICK
+        fn = tileNW == 16 ? tile_kernel_p16_nw16(val, prof) : tile_kernel_p16_nw8(val, prof);
     }
     int waves_per_cu;
     if (use_lds) {
@@ -1055,7 +1130,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     st.lds_bytes = use_lds ? (int32_t)lds_need : 0;
     st.setup_ms = m->setup_ms;
     st.kernel_ms = kernel_ms;
-    for (int32_t c = cb; c < ce; ++c) {
+    for (int32_t c : requested) {
       st.G += cs.G[c];
       st.D += cs.D[c];
       st.U += cs.U[c];

@@ -49,8 +49,10 @@ int32_t matrix_column_cost(const slimgpu_matrix_t* m, int64_t* cost);
 
 // EstimateModelCD + SaveModel on the device matrix.  Returns a host model
 // (slim_csr_t with both views) or nullptr with *status set.
+// columns/ncolumns (optional): solve exactly these item columns (distinct ids) instead of
+// the range [opt.col_begin, opt.col_end); every other column of the model comes back empty.
 slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
-                     int32_t* status);
+                     int32_t* status, const int32_t* columns = nullptr, int32_t ncolumns = 0);
 
 int32_t device_count();
 

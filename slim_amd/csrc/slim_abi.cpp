@@ -398,6 +398,24 @@ slim_t* SLIMGPU_Learn(slimgpu_matrix_t* mat, int32_t* ioptions, double* doptions
   return model;
 }
 
+slim_t* SLIMGPU_LearnColumns(slimgpu_matrix_t* mat, int32_t ncolumns, const int32_t* columns,
+                             int32_t* ioptions, double* doptions, slim_t* imodel,
+                             int32_t* r_status) {
+  set_error("");
+  int32_t status = SLIM_ERROR;
+  LearnOptions opt = decode_options(ioptions, doptions);
+  slim_csr_t* model = nullptr;
+  if (opt.algo != SLIM_ALGO_CD || ncolumns < 0 || (ncolumns > 0 && !columns)) {
+    set_error("SLIMGPU_LearnColumns: algo must be cd and the column list non-null");
+    status = SLIM_ERROR_INPUT;
+  } else {
+    static const int32_t none = 0;
+    model = learn_cd(mat, opt, as_csr(imodel), &status, columns ? columns : &none, ncolumns);
+  }
+  if (r_status) *r_status = status;
+  return model;
+}
+
 int32_t SLIMGPU_LastStats(slimgpu_stats_t* out) {
   if (!out) return SLIM_ERROR_INPUT;
   *out = last_stats();

@@ -146,8 +146,9 @@ class DeviceMatrix(object):
             raise RuntimeError("SLIMGPU_MatrixColumnCost failed")
         return cost
 
-    def learn(self, imodel=None, return_handle=False, **opts):
-        """SLIMGPU_Learn.  Returns (W as scipy CSC, stats dict)."""
+    def learn(self, imodel=None, return_handle=False, columns=None, **opts):
+        """SLIMGPU_Learn (or SLIMGPU_LearnColumns when an explicit list of item columns is
+        given).  Returns (W as scipy CSC, stats dict)."""
         iopt, dopt = make_options(**opts)
         st = C.c_int32(0)
         ih = None
@@ -158,8 +159,14 @@ class DeviceMatrix(object):
             else:  # scipy matrix -> temporary handle with a column view
                 tmp = _scipy_to_model_handle(self._lib, imodel)
                 ih = tmp
-        h = self._lib.SLIMGPU_Learn(self.handle, iopt.ctypes.data_as(C.c_void_p),
-                                    dopt.ctypes.data_as(C.c_void_p), ih, C.byref(st))
+        if columns is not None:
+            cols = np.ascontiguousarray(columns, dtype=np.int32)
+            h = self._lib.SLIMGPU_LearnColumns(self.handle, cols.size, cols,
+                                               iopt.ctypes.data_as(C.c_void_p),
+                                               dopt.ctypes.data_as(C.c_void_p), ih, C.byref(st))
+        else:
+            h = self._lib.SLIMGPU_Learn(self.handle, iopt.ctypes.data_as(C.c_void_p),
+                                        dopt.ctypes.data_as(C.c_void_p), ih, C.byref(st))
         if tmp is not None:
             self._lib.SLIM_FreeModel(C.byref(tmp))
         if not h:
