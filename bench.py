@@ -140,10 +140,10 @@ def main():
     fence()
     t0 = time.perf_counter()
     acc = dict(kernel_ms=0.0, alg_bytes=0.0, G=0, D=0, U=0, nnzW=0, sweeps=0, gather_ms=0.0)
-    first_b = None
+    last_b = None
     for i in range(args.steps):
         W, st, b = step(args.warmup + i)
-        first_b = b if first_b is None else first_b
+        last_b = b  # W holds the columns of THIS step: the CPU leg must sample from it
         for k in acc:
             acc[k] += st[k]
     fence()
@@ -198,7 +198,7 @@ def main():
             out["parity"] = ml100k_parity(local_rank)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, rowptr, rowind, rowval, nrows, ncols,
-                                               first_b, batch, opts, W)
+                                               last_b, batch, opts, W)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -105,7 +105,14 @@ enum {
                                     1/2/4/8/16/32 [auto: by tiles per cluster] */
   SLIM_OPTION_GPU_HEAVYTILES = 17,   /* tile kernels: the N most expensive tiles are
                                         solved first by larger clusters [auto]; 0 = off */
-  SLIM_OPTION_GPU_HEAVYCLUSTER = 18  /* size of those clusters, 2..32 [auto]          */
+  SLIM_OPTION_GPU_HEAVYCLUSTER = 18, /* size of those clusters, 2..32 [auto]          */
+  SLIM_OPTION_GPU_NGPUS = 19,      /* SLIM_Learn / Py_SLIM_Learn / Py_SLIM_Mselect: number of
+                                      GPUs of this node to shard the item columns over, one
+                                      host thread + stream per device, R replicated [1]   */
+  SLIM_OPTION_GPU_SHARDCOUNT = 20, /* SLIMGPU_Learn*: solve shard SHARDINDEX of SHARDCOUNT of  */
+  SLIM_OPTION_GPU_SHARDINDEX = 21  /* the requested columns: granules (32 columns of the
+                                      cost-ordered work list) INDEX, INDEX + COUNT, ...; a
+                                      column's visiting order does not depend on COUNT [1, 0] */
 };
 
 typedef enum {

@@ -705,25 +705,30 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
   const int32_t ntiles = (nwork + tileP - 1) / tileP;
   int nthreads = cfg->nthreads > 0 ? cfg->nthreads : 1;
 
+  /* shared per-tile state; the threads work on the MEMBERS of one tile at a time (a
+   * single tile of a 1M x 100K matrix is minutes of one core: the full-size parity tests
+   * solve one tile on all cores), which gives the same result for any thread count      */
+  float *key = (float *)malloc(sizeof(float) * (size_t)ncols * (size_t)tileP);
+  uint8_t *act = (uint8_t *)malloc((size_t)ncols * (size_t)tileP);
+  int32_t *uni = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
+  int64_t *Gm = (int64_t *)malloc(sizeof(int64_t) * (size_t)tileP);
+  int32_t nu = 0;
+
 #pragma omp parallel num_threads(nthreads) reduction(+ : error, objval)
   {
     double *x = (double *)calloc((size_t)ncols, sizeof(double));
     double *y = (double *)calloc((size_t)nrows, sizeof(double));
     double *yhat = (double *)calloc((size_t)nrows, sizeof(double));
     double *ATy = (double *)calloc((size_t)ncols, sizeof(double));
-    float *key = (float *)malloc(sizeof(float) * (size_t)ncols * (size_t)tileP);
-    uint8_t *act = (uint8_t *)malloc((size_t)ncols * (size_t)tileP);
-    int32_t *uni = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
-    int64_t *Gm = (int64_t *)malloc(sizeof(int64_t) * (size_t)tileP);
 
-#pragma omp for schedule(dynamic, 1)
     for (int32_t g = 0; g < ntiles; g++) {
       const int32_t base = g * tileP;
       const int32_t np = (nwork - base) < tileP ? (nwork - base) : tileP;
       /* active sets of the members (estimate.c:406-444, Gram-column aTy) */
-      memset(act, 0, (size_t)ncols * (size_t)tileP);
+#pragma omp for schedule(dynamic, 1)
       for (int32_t m = 0; m < np; m++) {
         const int32_t iC = order[base + m];
+        memset(act + (size_t)m * ncols, 0, (size_t)ncols);
         Gm[m] = 0;
         for (int64_t j = colptr[iC]; j < colptr[iC + 1]; j++) {
           const int32_t u = colind[j];
@@ -743,13 +748,17 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
           for (int64_t e = rowptr[u]; e < rowptr[u + 1]; e++) ATy[rowind[e]] = 0.0;
         }
       }
-      int32_t nu = 0;
-      for (int32_t i = 0; i < ncols; i++) {
-        int any = 0;
-        for (int32_t m = 0; m < np; m++) any |= act[(size_t)m * ncols + i];
-        if (any) uni[nu++] = i;
+#pragma omp single
+      {
+        nu = 0;
+        for (int32_t i = 0; i < ncols; i++) {
+          int any = 0;
+          for (int32_t m = 0; m < np; m++) any |= act[(size_t)m * ncols + i];
+          if (any) uni[nu++] = i;
+        }
       }
       /* every member: CoordinateDescent (cd.c:101-142) in the tile's order */
+#pragma omp for schedule(dynamic, 1)
       for (int32_t m = 0; m < np; m++) {
         const int32_t iC = order[base + m];
         const uint8_t *am = act + (size_t)m * ncols;
@@ -823,10 +832,11 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
         for (int64_t j = cs; j < ce; j++) y[colind[j]] = 0.0;
         for (int32_t k = 0; k < nu; k++) x[uni[k]] = 0.0;
         memset(yhat, 0, sizeof(double) * (size_t)nrows);
-      }
+      } /* (implicit barrier: the next tile rewrites act / key / uni) */
     }
-    free(x); free(y); free(yhat); free(ATy); free(key); free(act); free(uni); free(Gm);
+    free(x); free(y); free(yhat); free(ATy);
   }
+  free(key); free(act); free(uni); free(Gm);
 
   int64_t tnnz = 0;
   for (int32_t c = 0; c < ncols; c++) tnnz += nnzs[c];

@@ -46,6 +46,9 @@ class Opt(enum.IntEnum):
     GPU_CLUSTER = 16    # tile kernels: workgroups per tile (default auto)
     GPU_HEAVYTILES = 17    # tile kernels: most expensive tiles solved first by larger clusters
     GPU_HEAVYCLUSTER = 18  # ... of this many workgroups (default auto)
+    GPU_NGPUS = 19         # SLIM_Learn & co: shard the item columns over this many GPUs (default 1)
+    GPU_SHARDCOUNT = 20    # SLIMGPU_Learn*: solve one shard of the requested columns ...
+    GPU_SHARDINDEX = 21    # ... granules INDEX, INDEX + COUNT, ... of the cost-ordered work list
 
 
 for _o in Opt:

@@ -212,6 +212,10 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     if (grp >= grp_end) break;
     const uint64_t t_start = wall_clock64();
     const int base = grp * P;
+    // position of this tile in the unsharded work list (== grp for a single shard)
+    constexpr int PER = 32 / P;  // tiles per 32-column shard granule
+    const uint32_t gkey =
+        (uint32_t)(((grp / PER) * S.shard_count + S.shard_index) * PER + grp % PER);
     const int nprob = (S.nwork - base) < P ? (S.nwork - base) : P;
     if (tid < P) {
       s_item[tid] = tid < nprob ? S.order[base + tid] : -1;
@@ -535,7 +539,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       const bool live = !done_q;
       if (!__any(live) || s_abort) break;
       float dlt = 0.0f;
-      const PermCtx pc = perm_make((uint32_t)nunion, perm_key(S.seed, (uint32_t)grp, (uint32_t)t));
+      const PermCtx pc = perm_make((uint32_t)nunion, perm_key(S.seed, gkey, (uint32_t)t));
       if (nunion > 0) {
         // software pipeline on the visit scalars: the column id is read two visits ahead, the
         // slice offsets / x row / norms one visit ahead (values stay in VGPRs until consumed)

@@ -93,6 +93,10 @@ struct SolveArgs {
   int32_t* queue_hi;
   int64_t nnz_last;              // nnz - 1 (0 for an empty matrix): clamp for unconditional loads
   int32_t hi_prefetch;           // heavy phase: request the next visit's ids early
+  // shards: this launch solves granules (32 work-list entries) shard_index, shard_index +
+  // shard_count, ... of a larger cost-ordered list; the visiting permutation is keyed by the
+  // tile's position in THAT list, so a column's result does not depend on the shard count
+  int32_t shard_count, shard_index;
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;
   int64_t* out_off;

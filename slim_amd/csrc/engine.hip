@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <string>
@@ -56,6 +57,8 @@ struct slimgpu_matrix {
     void* p = nullptr;
     size_t bytes = 0;
   };
+  // copies of this matrix on other devices of the node (multi_gpu.cpp); owned by this handle
+  std::vector<slimgpu_matrix*> replicas;
   Buf ws_order, ws_cnt, ws_off, ws_stat_i, ws_stat_l, ws_stat_f, ws_misc, ws_arena_i, ws_arena_v,
       ws_slab, ws_xslab, ws_ulist, ws_trace, ws_mailbox, ws_atysh, ws_icolptr, ws_icolind,
       ws_icolval;
@@ -388,6 +391,8 @@ void ensure_cluster_split(slimgpu_matrix* m, int lg) {
 
 void destroy(slimgpu_matrix* m) {
   if (!m) return;
+  for (slimgpu_matrix* r : m->replicas) destroy(r);
+  m->replicas.clear();
   (void)hipSetDevice(m->device);
   if (m->owns_csr) {
     (void)hipFree(m->d_rowptr);
@@ -439,6 +444,9 @@ LearnOptions decode_options(const int32_t* io, const double* dopt) {
   o.cluster = geti(SLIM_OPTION_GPU_CLUSTER, 0);
   o.heavy_tiles = geti(SLIM_OPTION_GPU_HEAVYTILES, -1);
   o.heavy_cluster = geti(SLIM_OPTION_GPU_HEAVYCLUSTER, 0);
+  o.ngpus = std::max(1, geti(SLIM_OPTION_GPU_NGPUS, 1));
+  o.shard_count = std::max(1, geti(SLIM_OPTION_GPU_SHARDCOUNT, 1));
+  o.shard_index = geti(SLIM_OPTION_GPU_SHARDINDEX, 0);
   return o;
 }
 
@@ -559,6 +567,16 @@ slimgpu_matrix_t* matrix_from_device(int32_t nrows, int32_t ncols, const int64_t
 
 void matrix_free(slimgpu_matrix_t* m) { destroy(m); }
 
+void matrix_add_replica(slimgpu_matrix_t* m, slimgpu_matrix_t* replica) {
+  m->replicas.push_back(replica);
+}
+const std::vector<slimgpu_matrix_t*>& matrix_replicas(const slimgpu_matrix_t* m) {
+  return m->replicas;
+}
+void matrix_adopt_csr(slimgpu_matrix_t* m) { m->owns_csr = true; }
+int32_t matrix_device(const slimgpu_matrix_t* m) { return m->device; }
+void matrix_set_setup_ms(slimgpu_matrix_t* m, double ms) { m->setup_ms = ms; }
+
 int32_t matrix_info(const slimgpu_matrix_t* m, int32_t* nrows, int32_t* ncols, int64_t* nnz) {
   if (!m) return SLIM_ERROR_INPUT;
   if (nrows) *nrows = m->nrows;
@@ -613,7 +631,7 @@ int round_up(int v, int q) { return (v + q - 1) / q * q; }
 }  // namespace
 
 slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
-                     int32_t* status, const int32_t* columns, int32_t ncolumns) {
+                     int32_t* status, const int32_t* columns, int32_t ncolumns, bool row_view) {
   const double t_begin = now_ms();
   slimgpu_stats_t st;
   std::memset(&st, 0, sizeof(st));
@@ -642,9 +660,19 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     nwork = ncolumns;
   }
 
+  if (opt.shard_index < 0 || opt.shard_index >= opt.shard_count) {
+    set_error("SLIMGPU_Learn: shard index outside [0, shard count)");
+    return fail(SLIM_ERROR_INPUT);
+  }
+
   try {
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t stream = m->stream;
+    // One solve at a time per device and process: the tile kernel sizes its grid to the whole
+    // chip and its clusters need every member workgroup resident, which two concurrent
+    // launches (two host threads calling SLIM_Learn on one GPU) would not guarantee.
+    static std::mutex device_lock[64];
+    std::lock_guard<std::mutex> solve_guard(device_lock[m->device & 63]);
 
     // work list: most expensive columns first (longest-processing-time order)
     std::vector<int32_t> order((size_t)nwork);
@@ -652,9 +680,16 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       std::copy(columns, columns + nwork, order.begin());
     else
       std::iota(order.begin(), order.end(), cb);
-    const std::vector<int32_t> requested = order;
     std::stable_sort(order.begin(), order.end(),
                      [&](int32_t a, int32_t b) { return m->h_cost[a] > m->h_cost[b]; });
+    if (opt.shard_count > 1) {  // granules of 32 work-list entries, dealt round-robin
+      std::vector<int32_t> mine;
+      for (int32_t t = 0; t < nwork; ++t)
+        if ((t / 32) % opt.shard_count == opt.shard_index) mine.push_back(order[(size_t)t]);
+      order.swap(mine);
+      nwork = (int32_t)order.size();
+    }
+    const std::vector<int32_t> requested = order;
 
     // kernel flavour and geometry
     const int nrows_pad = round_up(std::max(m->nrows, 1), 64);
@@ -721,13 +756,32 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     size_t tile_r = 0, tile_x = 0, tile_u = 0;
     int clusterK = 1, cluster_lg = 0, nclusters = 0;
     int clusterHi = 0, hi_lg = 0, nheavy = 0, nclusters_hi = 0, auto_heavy = 0;
-    const int wg_slots = m->num_cus * (16 / tileNW);  // co-resident tile workgroups
+    // co-resident tile workgroups: what the occupancy calculator grants this instantiation
+    // (1 x 16 or 2 x 8 wavefronts per CU by design; fewer if the register or LDS footprint
+    // of a build ever grows), never more than the design assumes
+    int wg_slots = m->num_cus * (16 / tileNW);
     if (use_tile) {
+      int per_cu = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn),
+                                                           64 * tileNW, 0));
+      if (per_cu < 1) {
+        set_error("SLIMGPU_Learn: the tile kernel does not fit a compute unit of this device");
+        return fail(SLIM_ERROR);
+      }
+      wg_slots = m->num_cus * std::min(per_cu, 16 / tileNW);
+    }
+    // force_k1: no clusters, no heavy phase -- the geometry that needs no co-residency at all
+    // (fallback after a cluster timed out waiting for a member, e.g. under a CU mask)
+    auto plan_tiles = [&](const bool force_k1) {
+      clusterK = 1; cluster_lg = 0; nclusters = 0;
+      clusterHi = 0; hi_lg = 0; nheavy = 0; nclusters_hi = 0; auto_heavy = 0;
       const int ngroups_all = (nwork + tileP - 1) / tileP;
       // cluster size: share a tile among K workgroups when there are too few tiles to keep
       // every CU busy behind the slowest one (auto), or as requested
-      if (opt.cluster == 1 || opt.cluster == 2 || opt.cluster == 4 || opt.cluster == 8 ||
-          opt.cluster == 16 || opt.cluster == 32) {
+      if (force_k1) {
+        clusterK = 1;
+      } else if (opt.cluster == 1 || opt.cluster == 2 || opt.cluster == 4 || opt.cluster == 8 ||
+                 opt.cluster == 16 || opt.cluster == 32) {
         clusterK = opt.cluster;
       } else {
         // the heaviest tile runs ~7x the median (popular items need more sweeps): a
@@ -777,7 +831,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       }
       if (clusterHi != 2 && clusterHi != 4 && clusterHi != 8 && clusterHi != 16 && clusterHi != 32)
         clusterHi = std::max(16, std::min(4 * clusterK, kTileKMax));
-      if (clusterHi <= clusterK || nclusters * clusterK < clusterHi) nheavy = 0;
+      if (clusterHi <= clusterK || nclusters * clusterK < clusterHi || force_k1) nheavy = 0;
       if (nheavy > 0) {
         for (hi_lg = 0; (1 << hi_lg) < clusterHi; ++hi_lg) {}
         ensure_cluster_split(m, hi_lg);
@@ -797,7 +851,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         if (nclusters_hi < 1) nheavy = 0;
       }
       nwaves = nclusters * clusterK;  // workgroups launched
-    }
+    };
+    if (use_tile) plan_tiles(false);
 
     // device buffers
     int32_t* d_order = ws_get<int32_t>(m->ws_order, (size_t)nwork);
@@ -814,14 +869,18 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     unsigned long long* d_mailbox = nullptr;
     float* d_atysh = nullptr;
     const size_t mailbox_stride = 2 * (size_t)kTileKMax * (size_t)tileP + 8;
-    const size_t mailbox_words = (size_t)(std::max(nclusters, 1) + nclusters_hi) * mailbox_stride;
-    if (use_tile) {
+    size_t mailbox_words = 0;
+    auto alloc_tiles = [&]() {
+      mailbox_words = (size_t)(std::max(nclusters, 1) + nclusters_hi) * mailbox_stride;
       d_slab = ws_get<float>(m->ws_slab, tile_r * (size_t)nwaves);
       d_xslab = ws_get<float>(m->ws_xslab, tile_x * (size_t)nwaves);
       d_ulist = ws_get<int32_t>(m->ws_ulist, tile_u * (size_t)nwaves);
       d_mailbox = ws_get<unsigned long long>(m->ws_mailbox, mailbox_words);
       const size_t n_aty = (clusterK > 1 ? (size_t)nclusters : 0) + (nheavy > 0 ? (size_t)nclusters_hi : 0);
-      if (n_aty > 0) d_atysh = ws_get<float>(m->ws_atysh, tile_x * n_aty);
+      d_atysh = n_aty > 0 ? ws_get<float>(m->ws_atysh, tile_x * n_aty) : nullptr;
+    };
+    if (use_tile) {
+      alloc_tiles();
     } else if (!use_lds) {
       d_slab = ws_get<float>(m->ws_slab, vec_floats * (size_t)nwaves);
     }
@@ -898,6 +957,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     std::vector<int64_t> fin_off((size_t)ncols, 0);
     int64_t fin_total = 0;
 
+    bool cluster_fallback = false;
     for (int attempt = 0; attempt < 8 && !pending.empty(); ++attempt) {
       const int32_t npend = (int32_t)pending.size();
       int32_t* d_ai = ws_get<int32_t>(m->ws_arena_i, (size_t)arena_cap);
@@ -944,6 +1004,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.atyshared_hi = d_atysh ? d_atysh + (clusterK > 1 ? tile_x * (size_t)nclusters : 0) : nullptr;
       S.queue_hi = d_misc + 4;
       S.hi_prefetch = 1;
+      S.shard_count = opt.shard_count;
+      S.shard_index = opt.shard_index;
       S.nnz_last = m->nnz > 0 ? m->nnz - 1 : 0;
       if (const char* e = std::getenv("SLIM_GPU_HI_PREFETCH")) S.hi_prefetch = std::atoi(e);
       if (use_tile)
@@ -976,8 +1038,15 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
                    : std::max(1, std::min(npend, nwaves));
       // the heavy phase needs at least one whole big cluster in the launch
       if (S.nheavy > 0 && launch_waves < clusterHi) S.nheavy = 0;
+      // test hook: launch the last cluster one member short, which is what a CU mask or a
+      // second tenant does to a cluster -- exercises the timeout + fallback path below
+      int launch_now = launch_waves;
+      if (use_tile && clusterK > 1 && !cluster_fallback && std::getenv("SLIM_GPU_TEST_DROP_MEMBER")) {
+        launch_now -= 1;
+        S.nheavy = 0;
+      }
       HIP_TRY(hipEventRecord(ev0, stream));
-      hipLaunchKernelGGL(fn, dim3(launch_waves), dim3(use_tile ? 64 * tileNW : 64),
+      hipLaunchKernelGGL(fn, dim3(launch_now), dim3(use_tile ? 64 * tileNW : 64),
                          use_lds ? lds_need : 0, stream, A, S);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(ev1, stream));
@@ -1045,6 +1114,19 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       }
 
       if (h_misc[1] == 2) {
+        // A cluster waited ~10 s for a member that never published: not every workgroup of the
+        // launch was resident (CU mask, another tenant on the device).  The launch is void;
+        // solve everything that is pending again without clusters -- that geometry has no
+        // inter-workgroup dependency, so it completes on any number of compute units.
+        if (!cluster_fallback && (clusterK > 1 || nheavy > 0)) {
+          cluster_fallback = true;
+          std::fprintf(stderr, "[slim-gpu] tile cluster timed out (workgroups not co-resident); "
+                               "re-solving %d columns without clusters\n", npend);
+          plan_tiles(true);
+          alloc_tiles();
+          --attempt;  // the void launch does not count as an arena retry
+          continue;
+        }
         set_error("SLIMGPU_Learn: a tile cluster timed out waiting for a member workgroup "
                   "(were all workgroups resident?)");
         return fail(SLIM_ERROR);
@@ -1122,7 +1204,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       }
       colptr[c + 1] = colptr[c] + n;
     }
-    slim_csr_t* model = model_from_columns(ncols, colptr, colind, colval);
+    slim_csr_t* model = model_from_columns(ncols, colptr, colind, colval, row_view);
 
     st.ncols_solved = nwork;
     st.kernel = kernel;

@@ -20,6 +20,8 @@ struct LearnOptions {
   int32_t cluster = 0;  // tile-cluster size (0 = auto)
   int32_t heavy_tiles = -1;   // tiles solved by big clusters first (-1 = auto, 0 = none)
   int32_t heavy_cluster = 0;  // size of those clusters (0 = auto)
+  int32_t ngpus = 1;          // SLIM_Learn & co: devices to shard over (multi_gpu.cpp)
+  int32_t shard_count = 1, shard_index = 0;  // one shard of the cost-ordered work list
 };
 LearnOptions decode_options(const int32_t* ioptions, const double* doptions);
 
@@ -52,7 +54,26 @@ int32_t matrix_column_cost(const slimgpu_matrix_t* m, int64_t* cost);
 // columns/ncolumns (optional): solve exactly these item columns (distinct ids) instead of
 // the range [opt.col_begin, opt.col_end); every other column of the model comes back empty.
 slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
-                     int32_t* status, const int32_t* columns = nullptr, int32_t ncolumns = 0);
+                     int32_t* status, const int32_t* columns = nullptr, int32_t ncolumns = 0,
+                     bool row_view = true);
+
+// Replicas: copies of a staged matrix on other devices, owned by (and freed with) the
+// primary handle; matrix_adopt_csr hands the borrowed device CSR of a FromDevice matrix over
+// to the handle.
+void matrix_add_replica(slimgpu_matrix_t* m, slimgpu_matrix_t* replica);
+const std::vector<slimgpu_matrix_t*>& matrix_replicas(const slimgpu_matrix_t* m);
+void matrix_adopt_csr(slimgpu_matrix_t* m);
+int32_t matrix_device(const slimgpu_matrix_t* m);
+void matrix_set_setup_ms(slimgpu_matrix_t* m, double ms);
+
+// multi_gpu.cpp: the training matrix replicated on opt.ngpus GPUs of the node (the returned
+// handle is the copy on the first device and owns the others) and a solve sharded over all
+// copies of a handle, one host thread + stream per device.  With one device these are
+// matrix_from_host / learn_cd.
+slimgpu_matrix_t* multi_from_host(int32_t nrows, const ssize_t* rowptr, const int32_t* rowind,
+                                  const float* rowval, const LearnOptions& opt, int32_t* status);
+slim_csr_t* multi_learn(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
+                        int32_t* status, const int32_t* columns = nullptr, int32_t ncolumns = 0);
 
 int32_t device_count();
 

@@ -99,14 +99,14 @@ void csr_build_index(slim_csr_t* m, int what) {
 }
 
 slim_csr_t* model_from_columns(int32_t n, ssize_t* colptr, int32_t* colind,
-                               float* colval) {
+                               float* colval, bool row_view) {
   slim_csr_t* m = csr_new();
   if (!m) return nullptr;
   m->nrows = m->ncols = n;
   m->colptr = colptr;
   m->colind = colind;
   m->colval = colval;
-  csr_build_index(m, 1);
+  if (row_view) csr_build_index(m, 1);
   return m;
 }
 

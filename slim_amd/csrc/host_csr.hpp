@@ -38,8 +38,9 @@ void csr_build_index(slim_csr_t* m, int what);
 
 // Assemble a trained model from its column view (takes ownership of the three
 // malloc'd arrays) and add the row view (reference estimate.c:570-593).
+// row_view = false: the piece of a sharded solve, columns only (multi_gpu.cpp merges them).
 slim_csr_t* model_from_columns(int32_t n, ssize_t* colptr, int32_t* colind,
-                               float* colval);
+                               float* colval, bool row_view = true);
 
 // ---- consumers of W (host; reference predict.c, api.c:215-245) -------------
 

@@ -9,12 +9,13 @@ int main(int argc, char** argv) {
       {"ifmt", true},    {"binarize", false}, {"l1r", true},     {"l2r", true},
       {"optTol", true},  {"niters", true},    {"nnbrs", true},   {"simtype", true},
       {"algo", true},    {"ordered", false},  {"nthreads", true}, {"ipmdlfile", true},
-      {"dbglvl", true},  {"help", false}};
+      {"dbglvl", true},  {"ngpus", true},   {"help", false}};
   Args a = parse_args(argc, argv, specs);
   if (a.has("help") || a.pos.empty() || a.pos.size() > 2) {
     std::printf("\n Usage: slim_learn [options] train-file [model-file]\n"
                 "   -ifmt=csr|csrnv|cluto|ijv  -binarize  -l1r=f  -l2r=f  -optTol=f  -niters=i\n"
-                "   -nnbrs=i  -simtype=cos|jac|dotp  -algo=cd  -nthreads=i  -ipmdlfile=file  -dbglvl=i\n\n");
+                "   -nnbrs=i  -simtype=cos|jac|dotp  -algo=cd  -nthreads=i  -ipmdlfile=file  -dbglvl=i\n"
+                "   -ngpus=i   (engine extension: shard the item columns over i GPUs of this node)\n\n");
     return 0;
   }
   const Fmt fmt = parse_fmt(a.str("ifmt", "csr"));
@@ -55,6 +56,7 @@ int main(int argc, char** argv) {
   io[SLIM_OPTION_ALGO] = algo == "cd" ? SLIM_ALGO_CD : SLIM_ALGO_ADMM;
   io[SLIM_OPTION_NTHREADS] = a.integer("nthreads", 1);
   io[SLIM_OPTION_MAXNITERS] = niters;
+  if (a.has("ngpus")) io[SLIM_OPTION_GPU_NGPUS] = a.integer("ngpus", 1);
   dopt[SLIM_OPTION_L1R] = l1r;
   dopt[SLIM_OPTION_L2R] = l2r;
   dopt[SLIM_OPTION_OPTTOL] = optTol;

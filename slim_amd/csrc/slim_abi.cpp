@@ -7,6 +7,7 @@
 // with SLIM_ERROR* and a message -- there is no CPU fallback.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -37,9 +38,13 @@ slim_csr_t* learn_from_host(int32_t nrows, const ssize_t* rowptr, const int32_t*
     *status = SLIM_ERROR_INPUT;
     return nullptr;
   }
-  slimgpu_matrix_t* mat = matrix_from_host(nrows, rowptr, rowind, rowval, opt, status);
+  // ngpus (option slot 19, or SLIM_GPU_NGPUS in the environment for callers that cannot set
+  // it -- the unchanged reference CLIs and Python wrapper): one host thread per device
+  if (ioptions == nullptr || ioptions[SLIM_OPTION_GPU_NGPUS] == -1)
+    if (const char* e = std::getenv("SLIM_GPU_NGPUS")) opt.ngpus = std::max(1, std::atoi(e));
+  slimgpu_matrix_t* mat = multi_from_host(nrows, rowptr, rowind, rowval, opt, status);
   if (!mat) return nullptr;
-  slim_csr_t* model = learn_cd(mat, opt, imodel, status);
+  slim_csr_t* model = multi_learn(mat, opt, imodel, status);
   if (model && (opt.dbglvl & SLIM_DBG_TIME)) {  // timing.c:27-45
     const slimgpu_stats_t& s = last_stats();
     std::printf("\nTiming Information -------------------------------------------------");
@@ -187,8 +192,10 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
   // R goes to HBM once for the whole grid (the reference re-runs
   // CreateTrainingMatrix inside every SLIM_Learn call, pyapi.c:295-297)
   int32_t status = SLIM_ERROR;
+  if (ioptions == nullptr || ioptions[SLIM_OPTION_GPU_NGPUS] == -1)
+    if (const char* e = std::getenv("SLIM_GPU_NGPUS")) base.ngpus = std::max(1, std::atoi(e));
   slimgpu_matrix_t* mat =
-      matrix_from_host(trn->nrows, trn->rowptr, trn->rowind, trn->rowval, base, &status);
+      multi_from_host(trn->nrows, trn->rowptr, trn->rowind, trn->rowval, base, &status);
   if (!mat) return status;
 
   const int32_t trn_ncols = max_index_plus_one(trn->rowptr[trn->nrows], trn->rowind);
@@ -217,7 +224,7 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
       opt.l1r = arrayl1[a];
       opt.l2r = arrayl2[b];
       slim_csr_t* prev = model;  // warm start from the previous cell
-      model = learn_cd(mat, opt, prev, &status);
+      model = multi_learn(mat, opt, prev, &status);
       csr_free(prev);
       if (!model) {
         rc = status;
@@ -346,7 +353,7 @@ slimgpu_matrix_t* SLIMGPU_MatrixFromHost(int32_t nrows, const ssize_t* rowptr,
   set_error("");
   int32_t status = SLIM_ERROR;
   slimgpu_matrix_t* m =
-      matrix_from_host(nrows, rowptr, rowind, rowval, decode_options(ioptions, nullptr), &status);
+      multi_from_host(nrows, rowptr, rowind, rowval, decode_options(ioptions, nullptr), &status);
   if (r_status) *r_status = status;
   return m;
 }
@@ -392,7 +399,7 @@ slim_t* SLIMGPU_Learn(slimgpu_matrix_t* mat, int32_t* ioptions, double* doptions
     set_error("SLIMGPU_Learn: only algo=cd is implemented");
     status = SLIM_ERROR_INPUT;
   } else {
-    model = learn_cd(mat, opt, as_csr(imodel), &status);
+    model = multi_learn(mat, opt, as_csr(imodel), &status);
   }
   if (r_status) *r_status = status;
   return model;
@@ -410,7 +417,7 @@ slim_t* SLIMGPU_LearnColumns(slimgpu_matrix_t* mat, int32_t ncolumns, const int3
     status = SLIM_ERROR_INPUT;
   } else {
     static const int32_t none = 0;
-    model = learn_cd(mat, opt, as_csr(imodel), &status, columns ? columns : &none, ncolumns);
+    model = multi_learn(mat, opt, as_csr(imodel), &status, columns ? columns : &none, ncolumns);
   }
   if (r_status) *r_status = status;
   return model;

@@ -1,12 +1,16 @@
-"""Multi-GPU SLIM training: one process per GPU, item columns block-partitioned.
+"""Multi-GPU SLIM training, one process per GPU (the in-process form -- one host thread per
+device behind SLIM_Learn, option slot 19 -- lives in csrc/multi_gpu.cpp).
 
 Item columns are independent given the read-only rating matrix
 (/root/reference/src/libslim/estimate.c:402-403 is a parallel-for with no
 cross-iteration state), so the job shards with NO collective inside the solve:
   1. R is replicated: rank 0's CSR is broadcast once (RCCL over xGMI), every rank
      builds its own column view;
-  2. each rank solves one contiguous block of item columns, blocks balanced by the
-     engine's per-column cost proxy;
+  2. each rank solves its share of the item columns: either shard `rank` of `world` of the
+     engine's cost-ordered work list (granules of 32 columns dealt round-robin, so every
+     rank gets the same mix of popular and unpopular items and a column's result does not
+     depend on the number of ranks), or one contiguous block balanced by the engine's
+     per-column cost proxy (partition_columns);
   3. the learned columns are gathered (counts, then padded payload all-gather --
      RCCL has no gatherv) and every rank assembles the full W.
 torch.distributed is the transport ("nccl" == RCCL on ROCm, "gloo" for CPU tests).
@@ -37,7 +41,7 @@ def broadcast_csr(rowptr, rowind, rowval, src=0, group=None):
     import torch
     import torch.distributed as dist
     rank = dist.get_rank(group)
-    dev = rowptr.device if rank == src else _default_device()
+    dev = rowptr.device if rank == src else _default_device(group)
     meta = torch.zeros(3, dtype=torch.int64, device=dev)
     if rank == src:
         meta[0], meta[1] = rowptr.numel(), rowind.numel()
@@ -56,19 +60,19 @@ def broadcast_csr(rowptr, rowind, rowval, src=0, group=None):
     return rowptr, rowind, rowval
 
 
-def _default_device():
+def _default_device(group=None):
     import torch
     import torch.distributed as dist
-    if dist.get_backend() == "nccl":
+    if dist.get_backend(group) == "nccl":
         return torch.device("cuda", torch.cuda.current_device())
     return torch.device("cpu")
 
 
 def gather_model(W_local, group=None, dst=None):
     """All-gather column-disjoint pieces of W (scipy CSC, full n x n shape, only this
-    rank's columns populated) into the complete model -- on every rank, or (dst given)
-    assembled on rank ``dst`` only; the other ranks take part in the collectives and
-    return None."""
+    rank's columns populated -- a contiguous block or an interleaved shard) into the
+    complete model -- on every rank, or (dst given) assembled on rank ``dst`` only; the
+    other ranks take part in the collectives and return None."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -76,13 +80,11 @@ def gather_model(W_local, group=None, dst=None):
     n = W_local.shape[1]
     if world == 1:
         return W_local
-    dev = _default_device()
-    counts = torch.from_numpy(np.diff(W_local.indptr).astype(np.int64)).to(dev)
-    dist.all_reduce(counts, group=group)  # blocks are disjoint: the sum is the concatenation
-    nnz_local = torch.tensor([W_local.nnz], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, nnz_local, group=group)
-    sizes = [int(s) for s in sizes]
+    dev = _default_device(group)
+    mine = torch.from_numpy(np.diff(W_local.indptr).astype(np.int32)).to(dev)
+    per_rank = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(per_rank, mine, group=group)  # column counts of every rank
+    sizes = [int(c.sum()) for c in per_rank]
     pad = max(max(sizes), 1)
     ind = torch.zeros(pad, dtype=torch.int32, device=dev)
     val = torch.zeros(pad, dtype=torch.float32, device=dev)
@@ -94,35 +96,54 @@ def gather_model(W_local, group=None, dst=None):
     dist.all_gather(all_val, val, group=group)
     if dst is not None and dist.get_rank(group) != dst:
         return None
-    # rank r's entries are the columns of its block in ascending column order, and blocks
-    # ascend with the rank, so concatenation in rank order is the global CSC order --
-    # provided every rank's populated columns form one contiguous block.
-    indices = np.concatenate([t[:s].cpu().numpy() for t, s in zip(all_ind, sizes)])
-    data = np.concatenate([t[:s].cpu().numpy() for t, s in zip(all_val, sizes)])
-    indptr = np.concatenate([[0], np.cumsum(counts.cpu().numpy())])
+    # every column is populated by at most one rank: its entries go to the column's slot of
+    # the global CSC, in the order the owner holds them
+    counts = [c.cpu().numpy().astype(np.int64) for c in per_rank]
+    total = np.sum(counts, axis=0)
+    indptr = np.concatenate([[0], np.cumsum(total)])
+    indices = np.empty(int(indptr[-1]), np.int32)
+    data = np.empty(int(indptr[-1]), np.float32)
+    for r in range(world):
+        if sizes[r] == 0:
+            continue
+        local_ptr = np.concatenate([[0], np.cumsum(counts[r])])
+        dest = np.repeat(indptr[:-1] - local_ptr[:-1], counts[r]) + np.arange(sizes[r])
+        indices[dest] = all_ind[r][:sizes[r]].cpu().numpy()
+        data[dest] = all_val[r][:sizes[r]].cpu().numpy()
     return sp.csc_matrix((data, indices, indptr), shape=(n, n))
 
 
-def learn_sharded(mat, group=None, **opts):
+STAT_KEYS = ("objval", "error", "nnzW", "G", "D", "U", "sweeps", "ncols_solved")
+
+
+def learn_sharded(mat, group=None, partition="shards", **opts):
     """SLIM_Learn over all ranks of ``group`` on a replicated DeviceMatrix.
-    Returns (full W on every rank, this rank's stats, this rank's (begin, end))."""
+    partition: "shards" (rank r solves shard r of the cost-ordered work list; the result of a
+    column does not depend on the world size) or "blocks" (contiguous cost-balanced blocks).
+    Returns (full W on every rank, this rank's stats + "totals", this rank's (begin, end) for
+    blocks or (rank, world) for shards)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    blocks = partition_columns(mat.column_cost(), world)
-    b, e = blocks[rank]
-    W_local, stats = mat.learn(col_begin=b, col_end=e, **opts)
+    if partition == "blocks":
+        blocks = partition_columns(mat.column_cost(), world)
+        b, e = blocks[rank]
+        W_local, stats = mat.learn(col_begin=b, col_end=e, **opts)
+    else:
+        b, e = rank, world
+        W_local, stats = mat.learn(shard=(rank, world), **opts)
     W = gather_model(W_local, group) if world > 1 else W_local
     # the reductions of EstimateModelCD (estimate.c:371-373: error, objval) and the solve
     # counters, summed over the ranks; per-rank values stay under their own names
     stats = dict(stats)
-    keys = [k for k in ("objval", "error", "nnzW", "G", "D", "U", "sweeps", "ncols_solved") if k in stats]
+    keys = list(STAT_KEYS)  # the same fixed list on every rank: the all-reduce sizes must match
     if world > 1 and keys:
         import torch
-        t = torch.tensor([float(stats[k]) for k in keys], dtype=torch.float64, device=_default_device())
+        t = torch.tensor([float(stats.get(k, 0.0)) for k in keys], dtype=torch.float64,
+                         device=_default_device(group))
         dist.all_reduce(t, group=group)
         totals = t.tolist()
     else:
-        totals = [float(stats[k]) for k in keys]
+        totals = [float(stats.get(k, 0.0)) for k in keys]
     stats["totals"] = dict(zip(keys, totals))
     return W, stats, (b, e)

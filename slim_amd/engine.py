@@ -18,7 +18,7 @@ KERNEL_AUTO, KERNEL_WAVE_LDS, KERNEL_WAVE_HBM, KERNEL_TILE, KERNEL_TILE16 = 0, 1
 
 def make_options(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=1, col_begin=None,
                  col_end=None, kernel=KERNEL_AUTO, device=None, dbglvl=0, cluster=None, nnbrs=0,
-                 simtype=0, heavy_tiles=None, heavy_cluster=None):
+                 simtype=0, heavy_tiles=None, heavy_cluster=None, ngpus=None, shard=None):
     iopt = np.full(SLIM_NOPTIONS, -1, dtype=np.int32)
     dopt = np.full(SLIM_NOPTIONS, -1.0, dtype=np.float64)
     iopt[Opt.DBGLVL] = dbglvl
@@ -39,6 +39,10 @@ def make_options(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=1, col_begin=
         iopt[Opt.GPU_HEAVYTILES] = heavy_tiles
     if heavy_cluster is not None:
         iopt[Opt.GPU_HEAVYCLUSTER] = heavy_cluster
+    if ngpus is not None:
+        iopt[Opt.GPU_NGPUS] = ngpus
+    if shard is not None:  # (index, count)
+        iopt[Opt.GPU_SHARDINDEX], iopt[Opt.GPU_SHARDCOUNT] = shard
     dopt[Opt.L1R], dopt[Opt.L2R], dopt[Opt.OPTTOL] = l1r, l2r, optTol
     return iopt, dopt
 

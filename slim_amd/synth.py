@@ -5,8 +5,8 @@ time, so they are generated where they are used -- on the GPU -- from a seed.
 
 Model: item popularity ~ 1/(rank + c)^0.8, user activity
 log-normal clipped to [5, 5000] and rescaled to the requested nnz, items drawn from
-the popularity law per user (duplicates inside a user are merged, so the realised nnz
-is slightly below the target), values either all 1.0 (implicit feedback) or ratings
+the popularity law per user without replacement (oversample, merge duplicates, keep a
+random subset of the wanted size), values either all 1.0 (implicit feedback) or ratings
 1..5 with P = (.05, .05, .10, .30, .50).  Output: CSR with ascending item ids inside
 each row, int64 rowptr, int32 rowind, float32 rowval.
 
@@ -48,28 +48,46 @@ def generate_csr(nrows, ncols, target_nnz, seed=1, ratings=False, device="cpu",
     cdf[-1] = 1.0
     relabel = torch.randperm(ncols, generator=gen, device=dev)
 
-    starts = torch.cumsum(deg, 0) - deg
-    total = int(deg.sum())
+    # Items are drawn WITHOUT replacement per user: every user draws
+    # ~1.5x its degree from the popularity law, duplicates are merged, and a uniformly random
+    # subset of exactly deg[u] of the distinct items is kept (random, not "the first by id":
+    # that would tie popularity to the id).  A user whose oversampled draw still holds fewer
+    # than deg[u] distinct items keeps them all (rare; the realised nnz is reported).
+    draws = (deg * 3 + 1) // 2 + 16
+    draws = torch.minimum(draws, torch.clamp(deg * 8, min=16))
+    dcum = torch.cumsum(draws, 0)
+    dstart = dcum - draws
     ind_parts, cnt_parts = [], []
     r0 = 0
-    cum = torch.cumsum(deg, 0)
     while r0 < nrows:
         # rows [r0, r1) whose draws fit one chunk
-        base = int(starts[r0])
-        r1 = int(torch.searchsorted(cum, torch.tensor([base + chunk_nnz], device=dev),
+        base = int(dstart[r0])
+        r1 = int(torch.searchsorted(dcum, torch.tensor([base + chunk_nnz], device=dev),
                                     right=True)[0])
         r1 = max(r1, r0 + 1)
         r1 = min(r1, nrows)
-        d = deg[r0:r1]
+        d = draws[r0:r1]
         n = int(d.sum())
         users = torch.repeat_interleave(torch.arange(r0, r1, device=dev, dtype=torch.int64), d)
         u = torch.rand(n, generator=gen, device=dev, dtype=torch.float32)
         items = relabel[torch.searchsorted(cdf, u).clamp_(max=ncols - 1)]
         key = users * ncols + items
+        del users, u, items
         key = torch.unique(key)  # sorted: by user, then item; duplicates merged
+        lu = (key // ncols) - r0  # local user of every distinct pair
+        have = torch.bincount(lu, minlength=r1 - r0)
+        first = torch.cumsum(have, 0) - have
+        # random rank of every pair inside its user: sort by (user, random tag)
+        tag = torch.randint(0, 1 << 31, (key.numel(),), generator=gen, device=dev, dtype=torch.int64)
+        pos = torch.argsort(lu * (1 << 31) + tag)
+        rank = torch.empty_like(pos)
+        rank[pos] = torch.arange(key.numel(), device=dev, dtype=torch.int64)
+        keep = (rank - first[lu]) < deg[r0:r1][lu]
+        del tag, pos, rank
+        key = key[keep]  # still sorted by (user, item)
         ind_parts.append((key % ncols).to(torch.int32))
         cnt_parts.append(torch.bincount((key // ncols) - r0, minlength=r1 - r0))
-        del users, u, items, key
+        del key, lu, keep
         r0 = r1
     rowind = torch.cat(ind_parts)
     counts = torch.cat(cnt_parts)
@@ -82,7 +100,7 @@ def generate_csr(nrows, ncols, target_nnz, seed=1, ratings=False, device="cpu",
             if nnz < (1 << 24) else _ratings_big(nnz, gen, dev)
     else:
         rowval = torch.ones(nnz, dtype=torch.float32, device=dev)
-    assert rowind.numel() == nnz and total >= nnz
+    assert rowind.numel() == nnz
     return rowptr, rowind, rowval
 
 

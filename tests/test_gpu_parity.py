@@ -667,3 +667,62 @@ def test_tile_clusters_kkt_on_synthetic_c4_shape():
                     kernel=KERNEL_WAVE_HBM)
     assert maxdiff(Wh[:, b:e], W[:, b:e]) <= 5e-5
     m.close()
+
+
+def test_staging_rejects_malformed_csr(ml100k):
+    """duplicate (user, item) pairs, ids outside [0, ncols) and broken row offsets must
+    come back as SLIM_ERROR_INPUT with a message instead of reaching the kernels."""
+    import ctypes as C
+    from slim_amd import _lib
+    lib = _lib.load()
+
+    def stage(ptr, ind, val):
+        st = C.c_int32(0)
+        h = lib.SLIMGPU_MatrixFromHost(len(ptr) - 1, np.asarray(ptr, np.intp),
+                                       np.asarray(ind, np.int32),
+                                       np.asarray(val, np.float32).ctypes.data_as(C.c_void_p),
+                                       None, C.byref(st))
+        if h:
+            hh = C.c_void_p(h)
+            lib.SLIMGPU_MatrixFree(C.byref(hh))
+        return bool(h), st.value, _lib.last_error()
+
+    ok, st, msg = stage([0, 2, 4], [0, 1, 1, 2], [1, 1, 1, 1])
+    assert ok and st == 1
+    ok, st, msg = stage([0, 3, 4], [0, 1, 1, 2], [1, 1, 1, 1])      # (0,1) twice
+    assert not ok and st == -2 and "duplicate" in msg
+    ok, st, msg = stage([0, 2, 4], [0, -1, 1, 2], [1, 1, 1, 1])     # negative id
+    assert not ok and st == -2 and "item id" in msg
+    ok, st, msg = stage([0, 3, 2, 4], [0, 1, 1, 2], [1, 1, 1, 1])   # offsets go backwards
+    assert not ok and st == -2 and "rowptr" in msg
+    # SLIM_Learn reports the same through r_status (the reference would crash or loop)
+    R, _ = ml100k
+    ind = R.indices.astype(np.int32).copy()
+    ind[1] = ind[0]
+    st = C.c_int32(0)
+    h = lib.SLIM_Learn(R.shape[0], R.indptr.astype(np.intp), ind,
+                       R.data.astype(np.float32).ctypes.data_as(C.c_void_p), None, None, None,
+                       C.byref(st))
+    assert not h and st.value == -2
+
+
+def test_learn_columns_explicit_set(ml100k, ml_dev, ml_gpu):
+    """SLIMGPU_LearnColumns: an explicit, unordered set of item columns gives exactly the columns
+    a range solve gives (per-item visiting order), everything else empty; bad lists are refused."""
+    cols = np.array([1500, 3, 700, 701, 50, 1682, 0], np.int32)
+    W, st = ml_dev.learn(seed=1, columns=cols)
+    assert st["ncols_solved"] == cols.size
+    assert maxdiff(W[:, cols], ml_gpu[0][:, cols]) == 0.0
+    assert W.nnz == ml_gpu[0][:, cols].nnz
+    with pytest.raises(RuntimeError):
+        ml_dev.learn(seed=1, columns=[1, 1])
+    with pytest.raises(RuntimeError):
+        ml_dev.learn(seed=1, columns=[5000])
+    # tile kernel: the list is one tile (cost order), the oracle walks the same tile
+    tile = np.arange(100, 132, dtype=np.int32)
+    Wt, _ = ml_dev.learn(seed=1, columns=tile, kernel=KERNEL_TILE, cluster=4)
+    R, _ = ml100k
+    cost = ml_dev.column_cost()
+    order = tile[np.argsort(-cost[tile], kind="stable")]
+    Wo = O.learn_cd_tile(R, tileP=32, order=order, seed=1, nthreads=8)
+    assert maxdiff(Wt[:, tile], Wo[:, tile]) <= 2e-5
