@@ -49,8 +49,12 @@ class _OracleMatrix(object):
         return np.array([deg[Rc.indices[Rc.indptr[c]:Rc.indptr[c + 1]]].sum()
                          for c in range(self.ncols)], dtype=np.int64)
 
-    def learn(self, col_begin=0, col_end=None, seed=1, **kw):
-        cols = np.arange(col_begin, col_end, dtype=np.int32)
+    def learn(self, col_begin=0, col_end=None, seed=1, shard=None, **kw):
+        cols = np.arange(col_begin, self.ncols if col_end is None else col_end, dtype=np.int32)
+        if shard is not None:   # the engine's shards: granules of 32 of the cost-ordered list
+            index, count = shard
+            order = self.O.tile_work_order(self.R, col_begin, self.ncols if col_end is None else col_end)
+            cols = np.sort(order[(np.arange(order.size) // 32) % count == index]).astype(np.int32)
         W, st, err, obj = self.O.learn_cd(self.R, order=self.O.ORDER_PERM, seed=seed,
                                           aty=self.O.ATY_GRAM, cols=cols, return_stats=True)
         return W, {"ncols_solved": len(cols), "objval": obj, "error": err, "nnzW": W.nnz}
@@ -77,7 +81,11 @@ def _worker(rank, world, port, out_dir):
             ptr = ind = val = None
         ptr, ind, val = broadcast_csr(ptr, ind, val, src=0)
         R = sp.csr_matrix((val.numpy(), ind.numpy(), ptr.numpy()))
-        W, stats, (b, e) = learn_sharded(_OracleMatrix(R), seed=3)
+        Ws, stats_s, (si, sc) = learn_sharded(_OracleMatrix(R), seed=3)      # shards (default)
+        assert (si, sc) == (rank, world)
+        W, stats, (b, e) = learn_sharded(_OracleMatrix(R), seed=3, partition="blocks")
+        assert abs(sp.csc_matrix(Ws) - sp.csc_matrix(W)).nnz == 0
+        assert stats_s["totals"]["ncols_solved"] == stats["totals"]["ncols_solved"]
         sp.save_npz(os.path.join(out_dir, "w%d.npz" % rank), sp.csc_matrix(W))
         np.save(os.path.join(out_dir, "b%d.npy" % rank), np.array([b, e, stats["ncols_solved"]]))
         np.save(os.path.join(out_dir, "t%d.npy" % rank),
