@@ -176,6 +176,23 @@ slim_t *SLIMGPU_LearnColumns(slimgpu_matrix_t *mat, int32_t ncolumns,
 int32_t SLIMGPU_Predict(int32_t nrcmds, slim_t *slimhandle, slim_t *trnhandle,
                         int32_t *output, float *scores);
 
+/* Py_SLIM_Predict_1vsk on the GPU (src/libslim/predict.c:77-133, pyapi.c:483-528): user u
+ * ranks negitems[u*nnegs .. +nnegs); scores and tie order are the host scorer's.  Model rows
+ * must be ascending by item id (the engine's models are); 1 <= nnegs <= 1024. */
+int32_t SLIMGPU_Predict1vsK(int32_t nrcmds, int32_t nnegs, slim_t *slimhandle,
+                            slim_t *trnhandle, int32_t *negitems, int32_t *output,
+                            float *scores);
+
+/* Leave-k-out evaluation of top-N lists on the GPU (src/programs/slim_predict.c:181-236,
+ * src/libslim/pyapi.c:309-366): lists[u*nrcmds .. +counts[u]) against row u of tsthandle;
+ * fmarker = SLIM_DetermineHeadAndTail over fm_ncols items.  metrics = {HR, HR_head,
+ * HR_tail, ARHR}, nvalid = {users with a test item, ... with a head item, ... with a tail
+ * item}: the figures of the reference's host loop (float accumulators, user order). */
+int32_t SLIMGPU_Evaluate(int32_t nusers, int32_t nrcmds, const int32_t *lists,
+                         const int32_t *counts, slim_t *tsthandle,
+                         const int32_t *fmarker, int32_t fm_ncols, double *metrics,
+                         int32_t *nvalid);
+
 /* Counters of the most recent solve on this thread. */
 typedef struct slimgpu_stats_t {
   int32_t ncols_solved;

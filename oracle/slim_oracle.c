@@ -217,7 +217,23 @@ typedef struct {
                               1: engine-style arithmetic (fp32 residual, fused) */
   int32_t nnbrs;           /* > 0: FSLIM, api.c:43,55-56 */
   int32_t simtype;         /* 0 cos, 1 jac, 2 dotp (slim.h:196-200) */
+  int32_t chunk;           /* omp dynamic chunk; 0 = 32, the reference's (estimate.c:402).
+                              Timing a SAMPLE of columns wants 1 (one column per thread) */
+  int32_t tile_first;      /* oracle_learn_cd_tile: walk only tiles [tile_first,           */
+  int32_t tile_count;      /*   tile_first + tile_count) of the work list (0 = all)         */
 } oracle_cfg_t;
+
+/* wall time of the estimate phase (the reference's LearnTmr, api.c:68-85) of the last
+ * oracle_learn_cd / oracle_learn_cd_tile call, without the setup (transpose, norms) */
+static double g_learn_seconds = 0.0;
+double oracle_learn_seconds(void) { return g_learn_seconds; }
+static double now_seconds(void) {
+#ifdef _OPENMP
+  return omp_get_wtime();
+#else
+  return 0.0;
+#endif
+}
 
 static void fkv_sortd_stable(fkv_t *a, int64_t n);
 
@@ -441,6 +457,8 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
   int nthreads = cfg->nthreads > 0 ? cfg->nthreads : 1;
   if (stats) memset(stats, 0, sizeof(oracle_colstat_t) * (size_t)ncols);
 
+  const int chunk = cfg->chunk > 0 ? cfg->chunk : 32;
+  const double t_learn0 = now_seconds();
 #pragma omp parallel num_threads(nthreads) reduction(+ : error, objval)
   {
     /* per-thread dense work vectors, estimate.c:382-385 */
@@ -463,7 +481,7 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
                       ((uint32_t)tid * 0x85EBCA6Bu + 1u);
     if (lstate == 0) lstate = 1;
 
-#pragma omp for schedule(dynamic, 32) /* estimate.c:402 */
+#pragma omp for schedule(dynamic, chunk) /* estimate.c:402: chunk = 32 */
     for (int32_t w = 0; w < nwork; w++) {
       const int32_t iC = colsel ? colsel[w] : w;
       const int64_t cs = colptr[iC], ce = colptr[iC + 1];
@@ -638,6 +656,7 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
     free(nmark);
     free(ncand);
   }
+  g_learn_seconds = now_seconds() - t_learn0;
 
   /* estimate.c:570-589 SaveModel, column view */
   int64_t tnnz = 0;
@@ -713,6 +732,10 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
   int32_t *uni = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
   int64_t *Gm = (int64_t *)malloc(sizeof(int64_t) * (size_t)tileP);
   int32_t nu = 0;
+  const int32_t g_begin = cfg->tile_count > 0 ? cfg->tile_first : 0;
+  const int32_t g_end =
+      cfg->tile_count > 0 && g_begin + cfg->tile_count < ntiles ? g_begin + cfg->tile_count : ntiles;
+  const double t_learn0 = now_seconds();
 
 #pragma omp parallel num_threads(nthreads) reduction(+ : error, objval)
   {
@@ -721,7 +744,7 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
     double *yhat = (double *)calloc((size_t)nrows, sizeof(double));
     double *ATy = (double *)calloc((size_t)ncols, sizeof(double));
 
-    for (int32_t g = 0; g < ntiles; g++) {
+    for (int32_t g = g_begin; g < g_end; g++) {
       const int32_t base = g * tileP;
       const int32_t np = (nwork - base) < tileP ? (nwork - base) : tileP;
       /* active sets of the members (estimate.c:406-444, Gram-column aTy) */
@@ -836,6 +859,7 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
     }
     free(x); free(y); free(yhat); free(ATy);
   }
+  g_learn_seconds = now_seconds() - t_learn0;
   free(key); free(act); free(uni); free(Gm);
 
   int64_t tnnz = 0;
@@ -944,6 +968,52 @@ int32_t oracle_get_topn(int32_t ncols, const int64_t *wrowptr,
   free(marker);
   free(cand);
   return n;
+}
+
+/* predict.c:77-133 GetRec_1vsk + pyapi.c:483-528 Py_SLIM_Predict_1vsk: user u ranks the
+ * nnegs candidates negitems[u*nnegs ..]; a candidate id repeated in the list scores through
+ * its LAST position (predict.c:94-96), ids outside [0, ncols) stay candidates with score 0;
+ * float accumulation in history order; sort descending (stable here: upstream leaves ties
+ * undefined), take nrcmds.                                                              */
+int32_t oracle_predict_1vsk(int32_t ncols, const int64_t *wrowptr,
+                            const int32_t *wrowind, const float *wrowval,
+                            int32_t nusers, const int64_t *hptr, const int32_t *hind,
+                            const float *hval, int32_t nrcmds, int32_t nnegs,
+                            const int32_t *negitems, int32_t *out, float *scores) {
+  int32_t *marker = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
+  fkv_t *cand = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)(nnegs > 0 ? nnegs : 1));
+  for (int32_t i = 0; i < ncols; i++) marker[i] = -2;
+  for (int32_t u = 0; u < nusers; u++) {
+    const int32_t *neg = negitems + (int64_t)u * nnegs;
+    int32_t ncand = 0;
+    for (int32_t c = 0; c < nnegs; c++) { /* predict.c:91-101 */
+      cand[ncand].val = neg[c];
+      cand[ncand].key = 0.0f;
+      if (neg[c] >= 0 && neg[c] < ncols) marker[neg[c]] = ncand;
+      ncand++;
+    }
+    for (int64_t e = hptr[u]; e < hptr[u + 1]; e++) { /* predict.c:103-117 */
+      const int32_t i = hind[e];
+      if (i >= ncols || i < 0) continue;
+      const float rating = hval ? hval[e] : 1.0f;
+      for (int64_t j = wrowptr[i]; j < wrowptr[i + 1]; j++) {
+        const int32_t k = wrowind[j];
+        if (marker[k] == -2) continue;
+        cand[marker[k]].key += rating * wrowval[j];
+      }
+    }
+    fkv_sortd_stable(cand, ncand); /* predict.c:119 */
+    const int32_t n = ncand < nrcmds ? ncand : nrcmds;
+    for (int32_t r = 0; r < n; r++) {
+      out[(int64_t)u * nrcmds + r] = (int32_t)cand[r].val;
+      scores[(int64_t)u * nrcmds + r] = cand[r].key;
+    }
+    for (int32_t c = 0; c < nnegs; c++)
+      if (neg[c] >= 0 && neg[c] < ncols) marker[neg[c]] = -2;
+  }
+  free(marker);
+  free(cand);
+  return 1;
 }
 
 /* pyapi.c:530-563 Py_SLIM_Predict: top-N for every row of the history matrix;

@@ -23,7 +23,8 @@ class Cfg(C.Structure):
                 ("maxniters", C.c_int32), ("nthreads", C.c_int32),
                 ("order", C.c_int32), ("seed", C.c_uint32),
                 ("aty", C.c_int32), ("fp32", C.c_int32),
-                ("nnbrs", C.c_int32), ("simtype", C.c_int32)]
+                ("nnbrs", C.c_int32), ("simtype", C.c_int32),
+                ("chunk", C.c_int32), ("tile_first", C.c_int32), ("tile_count", C.c_int32)]
 
 
 class ColStat(C.Structure):
@@ -79,14 +80,15 @@ def _csr_arrays(R, binary=False):
 def learn_cd(R, l1r=1.0, l2r=1.0, optTol=1e-7, maxniters=10000, nthreads=1,
              order=ORDER_GLIBC, seed=1, aty=ATY_FULLSCAN, fp32=False,
              imodel=None, cols=None, binary=False, srand=1, return_stats=False,
-             nnbrs=0, simtype=0):
+             nnbrs=0, simtype=0, chunk=0):
     """Restated SLIM_Learn(algo=cd).  R: scipy CSR (ids used as given; model
     dimension = max id + 1, setup.c:117).  imodel: scipy sparse W of a previous
     solve (warm start through its column view).  Returns W as scipy CSC
     (column iC = regressors of item iC) [+ stats, error, objval]."""
     L = lib()
     nrows, ptr, ind, val = _csr_arrays(R, binary)
-    cfg = Cfg(l1r, l2r, optTol, maxniters, nthreads, order, seed, aty, int(fp32), nnbrs, simtype)
+    cfg = Cfg(l1r, l2r, optTol, maxniters, nthreads, order, seed, aty, int(fp32), nnbrs, simtype,
+              chunk, 0, 0)
     if order == ORDER_GLIBC and srand is not None:
         L.oracle_srand(C.c_uint32(srand))
     ic_ptr = ic_ind = ic_val = None
@@ -141,14 +143,17 @@ def tile_work_order(R, col_begin=0, col_end=None):
 
 
 def learn_cd_tile(R, tileP=32, order=None, l1r=1.0, l2r=1.0, optTol=1e-7, maxniters=10000,
-                  nthreads=1, seed=1, binary=False, return_stats=False):
-    """EstimateModelCD in the tile kernel's visiting order (see oracle_learn_cd_tile)."""
+                  nthreads=1, seed=1, binary=False, return_stats=False, tiles=None):
+    """EstimateModelCD in the tile kernel's visiting order (see oracle_learn_cd_tile).
+    tiles=(first, count): walk only those tiles of the work list (their position keys the
+    visiting order, so a tile of a larger launch can be checked alone)."""
     L = lib()
     nrows, ptr, ind, val = _csr_arrays(R, binary)
     if order is None:
         order = tile_work_order(R)
     order = np.ascontiguousarray(order, dtype=np.int32)
-    cfg = Cfg(l1r, l2r, optTol, maxniters, nthreads, ORDER_PERM, seed, ATY_GRAM, 0, 0, 0)
+    cfg = Cfg(l1r, l2r, optTol, maxniters, nthreads, ORDER_PERM, seed, ATY_GRAM, 0, 0, 0, 0,
+              tiles[0] if tiles else 0, tiles[1] if tiles else 0)
     ncols = int(ind.max()) + 1 if ind.size else 0
     stats = np.zeros(ncols, dtype=COLSTAT_DTYPE)
     wptr, wind, wval = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_float)()
@@ -195,6 +200,21 @@ def predict(W, H, nrcmds=10, binary=False):
     return out.reshape(nu, nrcmds), sc.reshape(nu, nrcmds)
 
 
+def predict_1vsk(W, H, negitems, nrcmds=10, binary=False):
+    """Py_SLIM_Predict_1vsk restated: negitems[nusers, nnegs] -> (ids filled with -1, scores)."""
+    L = lib()
+    ncols, wp, wi, wv = _w_rows(W)
+    nu, hp, hi, hv = _csr_arrays(H, binary)
+    neg = np.ascontiguousarray(negitems, dtype=np.int32).reshape(nu, -1)
+    out = np.full(nu * nrcmds, -1, dtype=np.int32)
+    sc = np.zeros(nu * nrcmds, dtype=np.float32)
+    L.oracle_predict_1vsk(C.c_int32(ncols), _p(wp, C.c_int64), _p(wi, C.c_int32), _p(wv, C.c_float),
+                          C.c_int32(nu), _p(hp, C.c_int64), _p(hi, C.c_int32), _p(hv, C.c_float),
+                          C.c_int32(nrcmds), C.c_int32(neg.shape[1]), _p(neg, C.c_int32),
+                          _p(out, C.c_int32), _p(sc, C.c_float))
+    return out.reshape(nu, nrcmds), sc.reshape(nu, nrcmds)
+
+
 def evaluate(W, trn, tst, nrcmds=10, binary=False):
     """HR/ARHR per pyapi.c:309-366.  Returns dict(hr, hr_head, hr_tail, arhr, nvalid...)."""
     L = lib()
@@ -220,6 +240,45 @@ def perm_index(p, n, key):
 
 def perm_key(seed, item, sweep):
     return int(lib().oracle_perm_key(seed, item, sweep))
+
+
+def learn_seconds():
+    """Wall time of the estimate phase of the last learn_cd / learn_cd_tile call (the
+    reference's LearnTmr), without the transpose and norms of the setup."""
+    lib().oracle_learn_seconds.restype = C.c_double
+    return float(lib().oracle_learn_seconds())
+
+
+def physical_cores():
+    """(physical cores, hardware threads) of this host, from /proc/cpuinfo."""
+    cores = set()
+    phys = core = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    n = os.cpu_count() or 1
+    return (len(cores) or n), n
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def max_threads():

@@ -39,12 +39,17 @@ def main():
     fcorr, wcorr = known / (gf * 1024), known / (sw * 1024)
     f, nf, tf = counter(fetch_csv, "cd_tile_kernel", "FETCH_SIZE")
     w, nw, tw = counter(write_csv, "cd_tile_kernel", "WRITE_SIZE")
-    bench = json.load(open(bench_json))
+    bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
     cfg = bench["config"]
+    kname = "cd_tile_kernel" if cfg["kernel"].startswith("tile") else "cd_wave_kernel"
+    f, nf, tf = counter(fetch_csv, kname, "FETCH_SIZE")
+    w, nw, tw = counter(write_csv, kname, "WRITE_SIZE")
     entry = {
         "match": {"workload": cfg["workload"].split(" ")[0], "scale": cfg["scale"],
+                  "seed": cfg.get("seed", 1),
                   "columns_per_step_per_gpu": cfg["columns_per_step_per_gpu"],
                   "kernel": cfg["kernel"], "binary": "binary values" in cfg["workload"]},
+        "kernel_hash": bench["roofline"].get("kernel_hash"),
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- "
                    "python bench.py --warmup 0 --steps 1 --cpu-seconds 0 (one pass per counter)",
         "launches": nf, "FETCH_SIZE_kb": f / max(nf, 1), "WRITE_SIZE_kb": w / max(nw, 1),
@@ -55,8 +60,19 @@ def main():
         "kernel_seconds_under_pmc": [round(x, 2) for x in tf + tw],
         "alg_bytes_per_launch_same_run": bench["roofline"]["alg_bytes_per_launch"],
     }
+    entry["traffic_over_algorithmic"] = entry["traffic_bytes_per_launch"] / max(
+        entry["alg_bytes_per_launch_same_run"], 1.0)
+    secs = entry["kernel_seconds_under_pmc"]
+    if secs:
+        entry["physical_GBps_under_pmc"] = entry["traffic_bytes_per_launch"] / (sum(secs) / len(secs)) / 1e9
     out = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    json.dump({"entries": [entry]}, open(out, "w"), indent=1)
+    try:
+        entries = json.load(open(out))["entries"]
+    except (OSError, ValueError, KeyError):
+        entries = []
+    # one entry per configuration: a new collection replaces the old one
+    entries = [e for e in entries if e.get("match") != entry["match"]] + [entry]
+    json.dump({"entries": entries}, open(out, "w"), indent=1)
     print(json.dumps(entry, indent=1))
 
 

@@ -89,6 +89,10 @@ _SIGNATURES = {
     "SLIMGPU_LearnColumns": (C.c_void_p, [C.c_void_p, C.c_int32, i32_1d, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.POINTER(C.c_int32)]),
     "SLIMGPU_Predict": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, i32_1d, f32_1d]),
+    "SLIMGPU_Predict1vsK": (C.c_int32, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, i32_1d,
+                                        i32_1d, f32_1d]),
+    "SLIMGPU_Evaluate": (C.c_int32, [C.c_int32, C.c_int32, i32_1d, i32_1d, C.c_void_p, i32_1d,
+                                     C.c_int32, f64_1d, i32_1d]),
     "SLIMGPU_LastStats": (C.c_int32, [C.POINTER(Stats)]),
     "SLIMGPU_LastColumnStats": (C.c_int32, [C.c_int32] + [C.c_void_p] * 6),
     "SLIMGPU_DeviceCount": (C.c_int32, []),

@@ -99,7 +99,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
   __shared__ int s_grp, s_nunion;
   __shared__ float s_tot[2][P];
   __shared__ int s_abort;
-  __shared__ long long s_G[P];  // Gram work counter per problem (reported with the column)
+  extern __shared__ uint32_t s_bits[];  // user bitmap of the screen pass (S.bm_words words)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -115,9 +115,8 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
   const int32_t* __restrict__ ubounds = HI ? S.ubounds_hi : S.ubounds;
   const int ubase = ubounds[mk], uend = ubounds[mk + 1];
   tile_gran_t* const mbox = (HI ? S.mailbox_hi : S.mailbox) + (int64_t)cid * (2 * kTileKMax * P + 8);
-  // cluster aTy accumulator
-  float* const aty_base = HI ? S.atyshared_hi : S.atyshared;
-  float* const aty_sh = aty_base ? aty_base + (int64_t)cid * S.x_stride : nullptr;
+  // this member's partial aTy of the tile's columns over ITS users, [ncols][P] (screen pass)
+  float* const part = S.atypart + (int64_t)blockIdx.x * S.x_stride;
   const int64_t* __restrict__ csplit = HI ? S.csplit_hi : S.csplit;  // [ncols][K+1] slice boundaries
   const int grp_end = HI ? S.nheavy : S.ngroups;
   if (tid == 0) s_abort = 0;
@@ -223,63 +222,105 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     }
     // -- clear the interleaved work vectors
     {
+      // (x needs no clearing: the active-set pass below assigns every entry)
       float4* r4 = reinterpret_cast<float4*>(r);
-      float4* x4 = reinterpret_cast<float4*>(x);
-      const int64_t nr4 = (int64_t)(uend - ubase) * (P / 4), nx4 = (int64_t)ncols * (P / 4);
+      const int64_t nr4 = (int64_t)(uend - ubase) * (P / 4);
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int64_t k = tid; k < nr4; k += NT) r4[k] = z;
-      for (int64_t k = tid; k < nx4; k += NT) x4[k] = z;
-      if (K > 1) {  // each member clears its share of the cluster's aTy accumulator
-        float4* a4 = reinterpret_cast<float4*>(aty_sh);
-        const int64_t lo = nx4 * mk / K, hi = nx4 * (mk + 1) / K;
-        for (int64_t k = lo + tid; k < hi; k += NT) a4[k] = z;
-      }
+      for (int k = tid; k < S.bm_words; k += NT) s_bits[k] = 0u;
     }
-    cluster_barrier();
-    float* aty = K > 1 ? aty_sh : x;
+    __syncthreads();
 
-    // -- y scatter + Gram column: wavefront w serves problems w, w+16 (estimate.c:406-421)
+    // -- y scatter (estimate.c:406-408): wavefront w serves problems w, w+NW; the users that
+    //    hold a rating of any of the tile's items are marked in the LDS bitmap (one bit per
+    //    1 << bm_shift users of this member's range)
+    const int sh = S.bm_shift;
 #pragma unroll
     for (int pp = 0; pp < PPW; ++pp) {
       const int pq = wave + pp * NW;
       const int witem = s_item[pq];
-      int64_t Gw = 0;
       if (witem >= 0) {
-        // this member's users of the column
         const int64_t cs = uni(csplit[(int64_t)witem * (K + 1) + mk]);
         const int64_t ce = uni(csplit[(int64_t)witem * (K + 1) + mk + 1]);
+        for (int64_t j = cs + lane; j < ce; j += 64) {
+          const int u = ci[j] - ubase;
+          r[(int64_t)u * P + pq] = HAS_VAL ? cv[j] : 1.0f;
+          const uint32_t bit = (uint32_t)u >> sh;
+          atomicOr(&s_bits[bit >> 5], 1u << (bit & 31));
+        }
+      }
+    }
+    __syncthreads();
+
+    // -- screen pass: aTy_i = a_i . y for EVERY column i, the P problems at once -- what the
+    //    reference computes by scanning the whole column view per item (estimate.c:412-421).
+    //    Each wavefront takes whole columns (no barrier, no exchange per column): it reads its
+    //    slice of the column in 64-nnz blocks, drops the users outside the tile's user set
+    //    (bitmap), compacts the rest through the cross-lane network and gathers their residual
+    //    lines, SL users x P problems per step.  No atomics: the sum of a column is formed in a
+    //    fixed order, so the screen aTy > l1 is reproducible for any rating values.  (The
+    //    Gram-column form, sum over the item's users of their rows, needs one device-scope
+    //    float atomic per touched (item, problem): 1.2 s of a 12.9 s median tile on C4, 7 s of
+    //    the 27 s heaviest tile.)
+    {
+      constexpr int GS = 8;  // gather steps in flight per lane
+      for (int i = wave; i < ncols; i += NW) {
+        const int64_t cs = uni(csplit[(int64_t)i * (K + 1) + mk]);
+        const int64_t ce = uni(csplit[(int64_t)i * (K + 1) + mk + 1]);
+        float acc = 0.0f;
+        // ids / values of the next block are requested before the current one is consumed
+        int u_n = 0;
+        float v_n = 0.0f;
+        if (cs + lane < ce) {
+          u_n = ci[cs + lane] - ubase;
+          v_n = HAS_VAL ? cv[cs + lane] : 1.0f;
+        }
         for (int64_t jb = cs; jb < ce; jb += 64) {
-          const int64_t j = jb + lane;
-          const bool ok = j < ce;
-          const int u_l = ok ? ci[j] : 0;
-          const float v_l = ok ? (HAS_VAL ? cv[j] : 1.0f) : 0.0f;
-          const int64_t rs_l = ok ? A.rowptr[u_l] : 0;
-          const int64_t re_l = ok ? A.rowptr[u_l + 1] : 0;
-          if (ok) r[(int64_t)(u_l - ubase) * P + pq] = v_l;
-          const int cnt = (int)((ce - jb) < 64 ? (ce - jb) : 64);
-          for (int k = 0; k < cnt; ++k) {
-            const int64_t rs = lane_bcast(rs_l, k), re = lane_bcast(re_l, k);
-            const float v = lane_bcast(v_l, k);
-            Gw += re - rs;
-            for (int64_t e = rs + lane; e < re; e += 64) {
-              const float rv = HAS_VAL ? A.rowval[e] : 1.0f;
-              atomicAdd(&aty[(int64_t)A.rowind[e] * P + pq], v * rv);
+          const bool ok = jb + lane < ce;
+          const int u = u_n;
+          const float v = v_n;
+          const int64_t jn = jb + 64 + lane;
+          if (jn < ce) {
+            u_n = ci[jn] - ubase;
+            v_n = HAS_VAL ? cv[jn] : 1.0f;
+          }
+          const uint32_t bit = (uint32_t)u >> sh;
+          const bool f = ok && ((s_bits[bit >> 5] >> (bit & 31)) & 1u);
+          const uint64_t m = __ballot(f);
+          const int cnt = __popcll(m);
+          if (cnt == 0) continue;
+          // compaction: the cnt marked entries move to lanes 0 .. cnt-1 (a full permutation,
+          // so every lane is written exactly once)
+          const int rank = __popcll(m & lane_lt);
+          const int dst = (f ? rank : cnt + (lane - rank)) << 2;
+          const int cu = __builtin_amdgcn_ds_permute(dst, u);
+          const float cw = HAS_VAL ? __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(v)))
+                                   : 1.0f;
+          for (int t0 = 0; t0 < cnt; t0 += SL * GS) {
+            float rr[GS];
+#pragma unroll
+            for (int g = 0; g < GS; ++g) {
+              const int src = t0 + g * SL + slot;
+              const int uu = __shfl(cu, src & 63);
+              rr[g] = 0.0f;
+              if (src < cnt)
+                rr[g] = *reinterpret_cast<const float*>(
+                    reinterpret_cast<const char*>(r) + (((uint32_t)uu * (uint32_t)(4 * P)) | ((uint32_t)q << 2)));
+            }
+#pragma unroll
+            for (int g = 0; g < GS; ++g) {
+              const int src = t0 + g * SL + slot;
+              const float w = HAS_VAL ? __shfl(cw, src & 63) : 1.0f;
+              acc += w * rr[g];
             }
           }
         }
-        if (K > 1 && mk == 0) {  // the counter G of the whole column (member 0 reports it)
-          int64_t gsum = 0;
-          for (int64_t j = uni(colptr[witem]) + lane; j < uni(colptr[witem + 1]); j += 64) {
-            const int u = ci[j];
-            gsum += A.rowptr[u + 1] - A.rowptr[u];
-          }
-          for (int off = 32; off > 0; off >>= 1) gsum += __shfl_xor(gsum, off);
-          Gw = gsum;
-        }
+        if (SL == 4) acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (slot == 0) part[(int64_t)i * P + q] = acc;  // one 128-byte line per column
       }
-      if (lane == 0) s_G[pq] = Gw;
     }
-    cluster_barrier();
+    cluster_barrier();  // every member's partial sums are published
 
     // -- active sets (estimate.c:433-444): x = 0 for active, -inf for inactive
     {
@@ -287,7 +328,10 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       for (int64_t idx = tid; idx < n; idx += NT) {
         const int i = (int)(idx >> LOGP), qq = (int)(idx & (P - 1));
         const int it = s_item[qq];
-        const bool act = it >= 0 && i != it && aty[idx] > l1;
+        float a = 0.0f;  // members in rank order: the same sum on every member
+        for (int k = 0; k < K; ++k)
+          a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
+        const bool act = it >= 0 && i != it && a > l1;
         x[idx] = act ? 0.0f : kInactive;
         if (act) atomicAdd(&s_na[qq], 1);
       }
@@ -650,7 +694,6 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         S.st_na[witem] = s_na[pq];
         S.st_sweeps[witem] = niters;
         S.st_conv[witem] = conv;
-        S.st_G[witem] = s_G[pq];
         S.st_D[witem] = Dw;
         S.st_U[witem] = Uw;
         S.st_err[witem] = err;

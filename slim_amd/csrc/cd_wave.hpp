@@ -80,7 +80,11 @@ struct SolveArgs {
   const int32_t* ubounds;        // [K+1] user-range boundaries
   const int64_t* csplit;         // [ncols][K+1] column slice boundaries (K = 1: colptr pairs)
   unsigned long long* mailbox;   // per cluster: 2 x 8 x P granules (+8), zeroed per launch
-  float* atyshared;              // per cluster: [ncols][P] aTy accumulator (K > 1)
+  float* atypart;                // per workgroup (stride x_stride): [ncols][P] partial aTy of
+                                 // the screen pass over the member's users
+  int32_t exact_gram;            // 1: no float atomics in the aTy sums (ratings are not small
+                                 // integers, where any order gives the same float)
+  int32_t bm_shift, bm_words;    // LDS user bitmap: one bit per 1 << bm_shift users, bm_words words
   // heavy-tile phase: the first nheavy tiles of the work list (the most expensive ones) are
   // solved by clusters of cluster_hi workgroups before the launch regroups into clusters
   // of `cluster` (cluster divides cluster_hi, so the small clusters nest in the big ones)
@@ -89,7 +93,6 @@ struct SolveArgs {
   const int32_t* ubounds_hi;
   const int64_t* csplit_hi;
   unsigned long long* mailbox_hi;
-  float* atyshared_hi;
   int32_t* queue_hi;
   int64_t nnz_last;              // nnz - 1 (0 for an empty matrix): clamp for unconditional loads
   int32_t hi_prefetch;           // heavy phase: request the next visit's ids early
@@ -211,11 +214,34 @@ __global__ __launch_bounds__(64) void cd_wave_kernel(const DevMatrix A, const So
     for (int i = lane; i < ncols; i += 64) aty[i] = 0.0f;
     wave_sync<USE_LDS>();
 
-    // -- 1+2: y scatter and Gram column.  64 users of the column per step;
+    // -- 1+2: y scatter and aTy.
+    int64_t G = 0;
+    if (S.exact_gram) {
+      // Ratings that are not small integers: float atomics would make the sums (and with them
+      // the strict screen aTy > l1) depend on the arrival order.  Form them as the reference
+      // does (estimate.c:412-421): a_i . y for every column i, one lane per column, users
+      // ascending -- a fixed order.  Costs one pass over the column view per item.
+      for (int64_t j = cs + lane; j < ce; j += 64) {
+        const int u = A.colind[j];
+        r[u] = HAS_VAL ? A.colval[j] : 1.0f;
+        G += A.rowptr[u + 1] - A.rowptr[u];
+      }
+      for (int off = 32; off > 0; off >>= 1) G += __shfl_xor(G, off);
+      wave_sync<USE_LDS>();
+      for (int ib = 0; ib < ncols; ib += 64) {
+        const int i = ib + lane;
+        float acc = 0.0f;
+        if (i < ncols) {
+          const int64_t s = A.colptr[i], e = A.colptr[i + 1];
+          for (int64_t k = s; k < e; ++k) acc += (HAS_VAL ? A.colval[k] : 1.0f) * r[A.colind[k]];
+          aty[i] = acc;
+        }
+      }
+    } else {
+    //    Gram column: 64 users of the column per step;
     //    each user's row is then spread over the lanes (ids inside a row are
     //    distinct, rows can collide -> float atomics, order-free for the
     //    integer-valued ratings of every shipped dataset)
-    int64_t G = 0;
     for (int64_t jb = cs; jb < ce; jb += 64) {
       const int64_t j = jb + lane;
       const bool ok = j < ce;
@@ -234,6 +260,7 @@ __global__ __launch_bounds__(64) void cd_wave_kernel(const DevMatrix A, const So
           atomicAdd(&aty[A.rowind[e]], v * rv);
         }
       }
+    }
     }
     wave_sync<USE_LDS>();
 

@@ -34,6 +34,7 @@ struct slimgpu_matrix {
   int64_t nnz = 0;
   bool binary = false;
   bool owns_csr = false;
+  bool exact_gram = false;  // ratings are not small integers: aTy sums formed in a fixed order
   // CSR
   int64_t* d_rowptr = nullptr;
   int32_t* d_rowind = nullptr;
@@ -60,7 +61,7 @@ struct slimgpu_matrix {
   // copies of this matrix on other devices of the node (multi_gpu.cpp); owned by this handle
   std::vector<slimgpu_matrix*> replicas;
   Buf ws_order, ws_cnt, ws_off, ws_stat_i, ws_stat_l, ws_stat_f, ws_misc, ws_arena_i, ws_arena_v,
-      ws_slab, ws_xslab, ws_ulist, ws_trace, ws_mailbox, ws_atysh, ws_icolptr, ws_icolind,
+      ws_slab, ws_xslab, ws_ulist, ws_trace, ws_mailbox, ws_part, ws_icolptr, ws_icolind,
       ws_icolval;
 };
 
@@ -197,7 +198,8 @@ __global__ void k_col_scalars(int32_t ncols, const int64_t* __restrict__ colptr,
                               const int32_t* __restrict__ colind,
                               const float* __restrict__ colval,
                               const int64_t* __restrict__ rowptr, float* __restrict__ csq,
-                              float* __restrict__ cnorm, int64_t* __restrict__ cost) {
+                              float* __restrict__ cnorm, int64_t* __restrict__ cost,
+                              int32_t* __restrict__ inexact) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -208,6 +210,9 @@ __global__ void k_col_scalars(int32_t ncols, const int64_t* __restrict__ colptr,
     for (int64_t k = s + lane; k < e; k += 64) {
       const float v = colval ? colval[k] : 1.0f;
       ss += v * v;
+      // float sums of products of small integers are exact in any order; anything else
+      // (fractional ratings, huge values) must not be accumulated with float atomics
+      if (v != rintf(v) || fabsf(v) > 2048.0f) atomicOr(inexact, 1);
       const int32_t u = colind[k];
       g += rowptr[u + 1] - rowptr[u];
     }
@@ -217,6 +222,7 @@ __global__ void k_col_scalars(int32_t ncols, const int64_t* __restrict__ colptr,
     }
     if (lane == 0) {
       if (!colval) ss = (float)(e - s);
+      if (!(ss < 16777216.0f)) atomicOr(inexact, 1);  // a dot product can reach |a_i||a_j|
       csq[c] = ss;
       cnorm[c] = sqrtf(ss);
       cost[c] = g;
@@ -345,15 +351,21 @@ void build_column_view(slimgpu_matrix* m) {
   } else {
     HIP_TRY(hipMemsetAsync(m->d_colptr, 0, sizeof(int64_t) * ((size_t)m->ncols + 1), st));
   }
+  int32_t* d_inexact = dev_alloc<int32_t>(1);
+  HIP_TRY(hipMemsetAsync(d_inexact, 0, sizeof(int32_t), st));
   hipLaunchKernelGGL(k_col_scalars, dim3(grid_for((int64_t)m->ncols * 64, 256, m->num_cus * 16)),
                      dim3(256), 0, st, m->ncols, m->d_colptr, m->d_colind, m->d_colval,
-                     m->d_rowptr, m->d_csq, m->d_cnorm, d_cost);
+                     m->d_rowptr, m->d_csq, m->d_cnorm, d_cost, d_inexact);
   HIP_TRY(hipGetLastError());
+  int32_t h_inexact = 0;
+  HIP_TRY(hipMemcpyAsync(&h_inexact, d_inexact, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   m->h_cost.resize((size_t)m->ncols);
   HIP_TRY(hipMemcpyAsync(m->h_cost.data(), d_cost, sizeof(int64_t) * (size_t)m->ncols,
                          hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipFree(d_cost));
+  HIP_TRY(hipFree(d_inexact));
+  m->exact_gram = h_inexact != 0;
 }
 
 // user ranges of equal nnz + per-column slice boundaries for clusters of size K = 1 << lg
@@ -411,7 +423,7 @@ void destroy(slimgpu_matrix* m) {
   for (slimgpu_matrix::Buf* b :
        {&m->ws_order, &m->ws_cnt, &m->ws_off, &m->ws_stat_i, &m->ws_stat_l, &m->ws_stat_f,
         &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_xslab, &m->ws_ulist,
-        &m->ws_trace, &m->ws_mailbox, &m->ws_atysh, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval})
+        &m->ws_trace, &m->ws_mailbox, &m->ws_part, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval})
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -628,6 +640,8 @@ KernelFn pick_kernel(bool lds, bool has_val) {
 
 int round_up(int v, int q) { return (v + q - 1) / q * q; }
 
+constexpr int kBitmapBytes = 32 * 1024;  // dynamic LDS of a tile workgroup (user bitmap)
+
 }  // namespace
 
 slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
@@ -763,7 +777,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     if (use_tile) {
       int per_cu = 0;
       HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn),
-                                                           64 * tileNW, 0));
+                                                           64 * tileNW, kBitmapBytes));
       if (per_cu < 1) {
         set_error("SLIMGPU_Learn: the tile kernel does not fit a compute unit of this device");
         return fail(SLIM_ERROR);
@@ -840,10 +854,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       }
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-      const size_t per_cl = ((tile_r + tile_x) * sizeof(float) + tile_u * sizeof(int32_t)) * clusterK +
-                            (clusterK > 1 || nheavy > 0 ? tile_x * sizeof(float) : 0);
+      const size_t per_cl = ((tile_r + 2 * tile_x) * sizeof(float) + tile_u * sizeof(int32_t)) * clusterK;
       const size_t have = free_b + m->ws_slab.bytes + m->ws_xslab.bytes + m->ws_ulist.bytes +
-                          m->ws_atysh.bytes;
+                          m->ws_part.bytes;
       const size_t budget = have > (size_t(6) << 30) ? have - (size_t(6) << 30) : have / 2;
       if ((size_t)nclusters * per_cl > budget) {
         nclusters = (int)std::max<size_t>(1, budget / per_cl);
@@ -867,7 +880,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     float* d_xslab = nullptr;
     int32_t* d_ulist = nullptr;
     unsigned long long* d_mailbox = nullptr;
-    float* d_atysh = nullptr;
+    float* d_part = nullptr;
+    int bm_shift = 0, bm_words = 1;
     const size_t mailbox_stride = 2 * (size_t)kTileKMax * (size_t)tileP + 8;
     size_t mailbox_words = 0;
     auto alloc_tiles = [&]() {
@@ -876,8 +890,13 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       d_xslab = ws_get<float>(m->ws_xslab, tile_x * (size_t)nwaves);
       d_ulist = ws_get<int32_t>(m->ws_ulist, tile_u * (size_t)nwaves);
       d_mailbox = ws_get<unsigned long long>(m->ws_mailbox, mailbox_words);
-      const size_t n_aty = (clusterK > 1 ? (size_t)nclusters : 0) + (nheavy > 0 ? (size_t)nclusters_hi : 0);
-      d_atysh = n_aty > 0 ? ws_get<float>(m->ws_atysh, tile_x * n_aty) : nullptr;
+      d_part = ws_get<float>(m->ws_part, tile_x * (size_t)nwaves);
+      // LDS user bitmap of the screen pass: one bit per 2^shift users of a member's range,
+      // at most kBitmapBytes
+      const int64_t range = (int64_t)(tile_r / (size_t)tileP);
+      bm_shift = 0;
+      while (((range >> bm_shift) + 31) / 32 * 4 > kBitmapBytes) ++bm_shift;
+      bm_words = (int)(((range >> bm_shift) + 1 + 31) / 32);
     };
     if (use_tile) {
       alloc_tiles();
@@ -995,13 +1014,15 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.ubounds = use_tile ? m->d_ubounds[cluster_lg] : nullptr;
       S.csplit = use_tile ? m->d_csplit[cluster_lg] : nullptr;
       S.mailbox = d_mailbox;
-      S.atyshared = clusterK > 1 ? d_atysh : nullptr;
+      S.exact_gram = (m->exact_gram || std::getenv("SLIM_GPU_EXACT_GRAM")) ? 1 : 0;
+      S.atypart = d_part;
+      S.bm_shift = bm_shift;
+      S.bm_words = bm_words;
       S.nheavy = use_tile ? nheavy : 0;
       S.cluster_hi = clusterHi;
       S.ubounds_hi = nheavy > 0 ? m->d_ubounds[hi_lg] : nullptr;
       S.csplit_hi = nheavy > 0 ? m->d_csplit[hi_lg] : nullptr;
       S.mailbox_hi = d_mailbox ? d_mailbox + (size_t)std::max(nclusters, 1) * mailbox_stride : nullptr;
-      S.atyshared_hi = d_atysh ? d_atysh + (clusterK > 1 ? tile_x * (size_t)nclusters : 0) : nullptr;
       S.queue_hi = d_misc + 4;
       S.hi_prefetch = 1;
       S.shard_count = opt.shard_count;
@@ -1047,7 +1068,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       }
       HIP_TRY(hipEventRecord(ev0, stream));
       hipLaunchKernelGGL(fn, dim3(launch_now), dim3(use_tile ? 64 * tileNW : 64),
-                         use_lds ? lds_need : 0, stream, A, S);
+                         use_lds ? lds_need : (use_tile ? sizeof(uint32_t) * (size_t)bm_words : 0),
+                         stream, A, S);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(ev1, stream));
 
@@ -1179,6 +1201,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     HIP_TRY(hipMemcpy(cs.sweeps.data(), d_sti + ncols, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cs.conv.data(), d_sti + 2 * (size_t)ncols, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cs.G.data(), d_stl, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
+    if (use_tile)  // the Gram work of a column is the staging pass's cost figure
+      for (int32_t c : requested) cs.G[(size_t)c] = m->h_cost[(size_t)c];
     HIP_TRY(hipMemcpy(cs.D.data(), d_stl + ncols, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cs.U.data(), d_stl + 2 * (size_t)ncols, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(h_err.data(), d_stf, sizeof(float) * (size_t)ncols, hipMemcpyDeviceToHost));

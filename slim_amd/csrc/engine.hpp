@@ -82,4 +82,14 @@ int32_t device_count();
 int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcmds,
                        int32_t* output, float* scores, int32_t* counts);
 
+// eval.hip: HR / ARHR of top-N lists against a test matrix on the GPU (the host loop's figures,
+// bit for bit), and the 1-vs-k protocol (every user ranks its own nnegs candidates).
+struct EvalResult;
+int32_t evaluate_device(int32_t nusers, int32_t nrcmds, const int32_t* lists, const int32_t* counts,
+                        const slim_csr_t* tst, const int32_t* fmarker, int32_t fm_ncols,
+                        EvalResult* out);
+int32_t predict_1vsk_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcmds,
+                            int32_t nnegs, const int32_t* negitems, int32_t* output,
+                            float* scores);
+
 }  // namespace slimamd

@@ -216,7 +216,7 @@ struct Eval {
   int nvalid = 0, nvalid_head = 0, nvalid_tail = 0;
 };
 
-inline Eval evaluate_lists(const Csr& tst, const std::vector<int32_t>& lists,
+inline Eval evaluate_lists_host(const Csr& tst, const std::vector<int32_t>& lists,
                            const std::vector<int32_t>& lens, int nrcmds, const int32_t* fmarker,
                            int32_t ncols) {
   Eval e;
@@ -257,6 +257,29 @@ inline Eval evaluate_lists(const Csr& tst, const std::vector<int32_t>& lists,
   e.hr_tail = e.nvalid_tail ? hr[1] / e.nvalid_tail : 0;
   e.arhr = e.nvalid ? arhr / e.nvalid : 0;
   return e;
+}
+
+// HR / ARHR on the GPU (SLIMGPU_Evaluate: the same figures as the host loop above); the host
+// loop serves when no device is usable -- evaluation, unlike training, may run anywhere.
+inline Eval evaluate_lists(Csr& tst, const std::vector<int32_t>& lists,
+                           const std::vector<int32_t>& lens, int nrcmds, const int32_t* fmarker,
+                           int32_t ncols) {
+  const int32_t nusers = std::min<int32_t>(tst.nrows, (int32_t)lens.size());
+  if (SLIMGPU_DeviceCount() > 0 && nusers > 0) {
+    slim_t* th = to_handle(tst);
+    double m[4];
+    int32_t nv[3];
+    const int32_t rc =
+        SLIMGPU_Evaluate(nusers, nrcmds, lists.data(), lens.data(), th, fmarker, ncols, m, nv);
+    Py_csr_free(th);
+    if (rc == SLIM_OK) {
+      Eval e;
+      e.hr = m[0]; e.hr_head = m[1]; e.hr_tail = m[2]; e.arhr = m[3];
+      e.nvalid = nv[0]; e.nvalid_head = nv[1]; e.nvalid_tail = nv[2];
+      return e;
+    }
+  }
+  return evaluate_lists_host(tst, lists, lens, nrcmds, fmarker, ncols);
 }
 
 inline void banner() {

@@ -235,9 +235,12 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
       std::vector<float> lsc((size_t)trn->nrows * nrcmds, 0.0f);
       const bool on_gpu = nrcmds <= 128 && predict_device(model, trn, nrcmds, lists.data(),
                                                           lsc.data(), lens.data()) == SLIM_OK;
-      const EvalResult ev = on_gpu ? evaluate(model, trn, tst, nrcmds, fmarker, ncols,
-                                              lists.data(), lens.data())
-                                   : evaluate(model, trn, tst, nrcmds, fmarker, ncols);
+      EvalResult ev;
+      if (!on_gpu)
+        ev = evaluate(model, trn, tst, nrcmds, fmarker, ncols);
+      else if (evaluate_device(std::min(trn->nrows, tst->nrows), nrcmds, lists.data(), lens.data(),
+                               tst, fmarker, ncols, &ev) != SLIM_OK)  // hit counting on the GPU
+        ev = evaluate(model, trn, tst, nrcmds, fmarker, ncols, lists.data(), lens.data());
       std::printf("l1r: %.2le l2r: %.2le nnz: %7zd hr: %.4f hr_head: %.4f hr_tail: %.4f "
                   "arhr: %.4f time: %.2lf\n",
                   opt.l1r, opt.l2r, model->rowptr[model->nrows], ev.hr, ev.hr_head, ev.hr_tail,
@@ -330,6 +333,12 @@ int32_t Py_SLIM_Predict_1vsk(int32_t nrcmds, int32_t nnegs, slim_t* slimhandle,
   const slim_csr_t* W = as_csr(slimhandle);
   const slim_csr_t* trn = as_csr(trnhandle);
   if (!W || !trn || !W->rowptr || !trn->rowptr || nrcmds < 0 || nnegs < 0) return SLIM_ERROR;
+  const int policy = predict_policy();
+  if (policy == 2 || (policy == 1 && nrcmds >= 1 && nnegs >= 1 && nnegs <= 1024 &&
+                      trn->nrows > 0 && device_count() > 0)) {
+    const int32_t rc = predict_1vsk_device(W, trn, nrcmds, nnegs, negitems, output, scores);
+    if (rc == SLIM_OK || policy == 2) return rc;  // (unsorted model rows etc.: host scorer)
+  }
   std::vector<int32_t> rids(nrcmds);
   std::vector<float> rsc(nrcmds);
   for (int32_t u = 0; u < trn->nrows; ++u) {
@@ -421,6 +430,27 @@ slim_t* SLIMGPU_LearnColumns(slimgpu_matrix_t* mat, int32_t ncolumns, const int3
   }
   if (r_status) *r_status = status;
   return model;
+}
+
+int32_t SLIMGPU_Predict1vsK(int32_t nrcmds, int32_t nnegs, slim_t* slimhandle, slim_t* trnhandle,
+                            int32_t* negitems, int32_t* output, float* scores) {
+  set_error("");
+  return predict_1vsk_device(as_csr(slimhandle), as_csr(trnhandle), nrcmds, nnegs, negitems, output,
+                             scores);
+}
+
+int32_t SLIMGPU_Evaluate(int32_t nusers, int32_t nrcmds, const int32_t* lists,
+                         const int32_t* counts, slim_t* tsthandle, const int32_t* fmarker,
+                         int32_t fm_ncols, double* metrics, int32_t* nvalid) {
+  set_error("");
+  if (!metrics || !nvalid) return SLIM_ERROR_INPUT;
+  EvalResult ev;
+  const int32_t rc =
+      evaluate_device(nusers, nrcmds, lists, counts, as_csr(tsthandle), fmarker, fm_ncols, &ev);
+  if (rc != SLIM_OK) return rc;
+  metrics[0] = ev.hr; metrics[1] = ev.hr_head; metrics[2] = ev.hr_tail; metrics[3] = ev.arhr;
+  nvalid[0] = ev.nvalid; nvalid[1] = ev.nvalid_head; nvalid[2] = ev.nvalid_tail;
+  return SLIM_OK;
 }
 
 int32_t SLIMGPU_LastStats(slimgpu_stats_t* out) {

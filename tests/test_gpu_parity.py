@@ -9,6 +9,7 @@ reference's own run-to-run noise):
   * HR@10 / ARHR on ml100k: equal to the reference's 0.3191 / 0.1504 (4 decimals)
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -500,10 +501,13 @@ def test_gpu_topn_ratings_short_lists_and_ties(automotive):
     m = DeviceMatrix.from_scipy(R)
     hm, _ = m.learn(l1r=20.0, l2r=1.0, niters=100, return_handle=True)  # sparse model: short lists
     hr = _wrap(lib, R)
+    from slim_amd.engine import model_to_scipy
+    ids_o, sc_o = O.predict(model_to_scipy(lib, hm, free=False), R, 20)   # the checker
     for env in TOPN_MODES:
         ids_g, sc_g, ids_c, sc_c = _predict_both(lib, hm, hr, R.shape[0], 20, env)
-        assert np.array_equal(ids_g, ids_c) and np.array_equal(sc_g, sc_c), env
-    assert (ids_c == -1).any()              # some users have fewer than 20 candidates
+        assert np.array_equal(ids_g, ids_o) and np.array_equal(sc_g, sc_o), env
+        assert np.array_equal(ids_c, ids_o) and np.array_equal(sc_c, sc_o), env
+    assert (ids_o == -1).any()              # some users have fewer than 20 candidates
     # a model with many exactly tied scores: W = all ones on a band
     n = 300
     Wt = sp.diags([np.ones(n - k, np.float32) for k in (1, 2, 3)], [1, 2, 3], format="csr")
@@ -513,9 +517,11 @@ def test_gpu_topn_ratings_short_lists_and_ties(automotive):
                   dtype=np.float32)
     H.data[:] = 1.0
     hh = _wrap(lib, sp.csr_matrix((H.data, H.indices, H.indptr), shape=(200, n)))
+    ids_o, sc_o = O.predict(Wt, H, 7)       # stable descending sort: ties in discovery order
     for env in TOPN_MODES:
         ids_g, sc_g, ids_c, sc_c = _predict_both(lib, ht, hh, 200, 7, env)
-        assert np.array_equal(ids_g, ids_c) and np.array_equal(sc_g, sc_c), env
+        assert np.array_equal(ids_g, ids_o) and np.array_equal(sc_g, sc_o), env
+        assert np.array_equal(ids_c, ids_o) and np.array_equal(sc_c, sc_o), env
     for h in (hr, hh):
         lib.Py_csr_free(h)
     for h in (C.c_void_p(hm), ht):
@@ -561,8 +567,10 @@ def test_gpu_topn_chunk_kernel_wide_model():
                 {"SLIM_TOPN_KERNEL": "chunk", "SLIM_TOPN_KEY": "64", "SLIM_TOPN_WAVES": "16"},
                 {"SLIM_TOPN_KERNEL": "wave"}):
         for N in (10, 32):
+            ids_o, sc_o = O.predict(W, H, N)
             ids_g, sc_g, ids_c, sc_c = _predict_both(lib, hW, hH, nu, N, env)
-            assert np.array_equal(ids_g, ids_c) and np.array_equal(sc_g, sc_c), (env, N)
+            assert np.array_equal(ids_g, ids_o) and np.array_equal(sc_g, sc_o), (env, N)
+            assert np.array_equal(ids_c, ids_o) and np.array_equal(sc_c, sc_o), (env, N)
     assert (ids_c[0] == -1).all() and (ids_c[2] >= 0).all()
     lib.Py_csr_free(hH)
     lib.SLIM_FreeModel(C.byref(hW))
@@ -726,3 +734,102 @@ def test_learn_columns_explicit_set(ml100k, ml_dev, ml_gpu):
     order = tile[np.argsort(-cost[tile], kind="stable")]
     Wo = O.learn_cd_tile(R, tileP=32, order=order, seed=1, nthreads=8)
     assert maxdiff(Wt[:, tile], Wo[:, tile]) <= 2e-5
+
+
+@pytest.mark.parametrize("kernel,geom", [(KERNEL_WAVE_LDS, {}), (KERNEL_WAVE_HBM, {}),
+                                         (KERNEL_TILE, {"cluster": 1}), (KERNEL_TILE, {"cluster": 4})])
+def test_fractional_ratings_are_reproducible(kernel, geom):
+    """with non-integer ratings the aTy sums may not depend on the arrival order
+    of float atomics (the strict screen aTy > l1, estimate.c:433-444, could flip between runs).
+    The screen sums are formed in a fixed order: five solves are bit-identical, and the active
+    sets are the oracle's (which accumulates in double)."""
+    rng = np.random.default_rng(11)
+    nu, ni = 700, 320
+    M = sp.random(nu, ni, density=0.08, random_state=rng, format="csr", dtype=np.float32)
+    M.data = rng.uniform(0.5, 5.0, M.nnz).astype(np.float32)        # fractional values
+    M.sort_indices()
+    m = DeviceMatrix.from_scipy(M)
+    runs = []
+    for _ in range(5):
+        W, st = m.learn(seed=1, l1r=0.7, l2r=0.5, kernel=kernel, **geom)
+        runs.append((W, m.column_stats().nacols.copy()))
+    for W, na in runs[1:]:
+        assert maxdiff(W, runs[0][0]) == 0.0 and np.array_equal(na, runs[0][1])
+    Wo, so, _, _ = O.learn_cd(M, l1r=0.7, l2r=0.5, order=O.ORDER_PERM, seed=1, aty=O.ATY_GRAM,
+                              nthreads=8, return_stats=True)
+    assert np.array_equal(runs[0][1], so["nacols"][:ni])
+    if kernel != KERNEL_TILE:      # per-item visiting order: visit-for-visit comparable
+        assert maxdiff(runs[0][0], Wo) <= 5e-5
+    m.close()
+
+
+# ---- SURVEY 8(f) #1, second half: HR / ARHR and the 1-vs-k protocol on the GPU --------------
+def test_gpu_evaluation_matches_oracle(ml100k, ml_dev, automotive):
+    """SLIMGPU_Evaluate (hit counting, HR / HR_head / HR_tail / ARHR of slim_predict.c:181-236,
+    pyapi.c:309-366) against the oracle's restatement of the host loop: equal figures, on
+    ml100k (one test item per user) and on Automotive (several, head and tail items)."""
+    lib = _lib.load()
+    for R, T in (ml100k, automotive[:2]):
+        R = sp.csr_matrix(R)
+        T = sp.csr_matrix(T)
+        m = DeviceMatrix.from_scipy(R)
+        hm, _ = m.learn(l1r=1.0, l2r=1.0, niters=100, seed=1, return_handle=True)
+        from slim_amd.engine import model_to_scipy
+        W = model_to_scipy(lib, hm, free=False)
+        hr = _wrap(lib, R)
+        ht = _wrap(lib, T)
+        for n in (10, 3):
+            ids = np.full(R.shape[0] * n, -1, np.int32)
+            sc = np.zeros(R.shape[0] * n, np.float32)
+            assert lib.SLIMGPU_Predict(n, hm, hr, ids, sc) == SLIM_OK
+            cnt = (ids.reshape(-1, n) >= 0).sum(1).astype(np.int32)
+            ncols = max(R.shape[1], T.shape[1], int(T.indices.max()) + 1)
+            fm = O.head_tail(R, ncols)
+            met = np.zeros(4)
+            nv = np.zeros(3, np.int32)
+            nu = min(R.shape[0], T.shape[0])
+            assert lib.SLIMGPU_Evaluate(nu, n, ids, cnt, ht, fm, ncols, met, nv) == SLIM_OK, _lib.last_error()
+            want = O.evaluate(W, R, T, n)
+            assert nv.tolist() == [want["nvalid"], want["nvalid_head"], want["nvalid_tail"]]
+            got = np.array(met, np.float32)
+            ref = np.array([want["hr"], want["hr_head"], want["hr_tail"], want["arhr"]], np.float32)
+            assert np.array_equal(got, ref), (got, ref)
+        for h in (hr, ht):
+            lib.Py_csr_free(h)
+        hh = C.c_void_p(hm)
+        lib.SLIM_FreeModel(C.byref(hh))
+        m.close()
+
+
+def test_gpu_1vsk_matches_oracle(ml100k, ml_gpu):
+    """Py_SLIM_Predict_1vsk / SLIMGPU_Predict1vsK against the oracle's restatement of
+    predict.c:77-133: ids and float scores equal, including repeated candidates (the last
+    position scores), out-of-range ids (score 0), ties (candidate order) and nnegs < nrcmds."""
+    lib = _lib.load()
+    R, _ = ml100k
+    W = ml_gpu[0]
+    from slim_amd.engine import _scipy_to_model_handle
+    hm = _scipy_to_model_handle(lib, W)
+    hr = _wrap(lib, R)
+    rng = np.random.default_rng(5)
+    nu = R.shape[0]
+    for nnegs, n in ((100, 10), (7, 10), (300, 25)):
+        neg = rng.integers(0, R.shape[1], size=(nu, nnegs)).astype(np.int32)
+        neg[:, 3] = neg[:, 1]                  # a repeated candidate
+        neg[5, 0], neg[6, 2] = -1, 5000        # ids outside the model
+        for env in (None, "cpu"):
+            out = np.full(nu * n, -1, np.int32)
+            sc = np.zeros(nu * n, np.float32)
+            if env:
+                os.environ["SLIM_PREDICT"] = env
+            try:
+                rc = (lib.Py_SLIM_Predict_1vsk if env else lib.SLIMGPU_Predict1vsK)(
+                    n, nnegs, hm, hr, neg.reshape(-1).copy(), out, sc)
+            finally:
+                os.environ.pop("SLIM_PREDICT", None)
+            assert rc == SLIM_OK, _lib.last_error()
+            ids_o, sc_o = O.predict_1vsk(W, R, neg, n)
+            assert np.array_equal(out.reshape(nu, n), ids_o), (nnegs, n, env)
+            assert np.array_equal(sc.reshape(nu, n), sc_o), (nnegs, n, env)
+    lib.Py_csr_free(hr)
+    lib.SLIM_FreeModel(C.byref(hm))
