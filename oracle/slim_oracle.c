@@ -743,6 +743,9 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
     double *y = (double *)calloc((size_t)nrows, sizeof(double));
     double *yhat = (double *)calloc((size_t)nrows, sizeof(double));
     double *ATy = (double *)calloc((size_t)ncols, sizeof(double));
+    int32_t *nmark = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
+    fkv_t *ncand = (fkv_t *)malloc(sizeof(fkv_t) * (size_t)ncols);
+    for (int32_t i = 0; i < ncols; i++) nmark[i] = -1;
 
     for (int32_t g = g_begin; g < g_end; g++) {
       const int32_t base = g * tileP;
@@ -760,6 +763,14 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
             ATy[rowind[e]] += v * (rowval ? rowval[e] : 1.0);
           Gm[m] += rowptr[u + 1] - rowptr[u];
         }
+        if (cfg->nnbrs > 0) { /* estimate.c:424-431 FSLIM: the neighbour list, no l1 screen */
+          const int32_t nn =
+              find_neighbors(cfg, nrows, rowptr, rowind, rowval, &A, iC, nmark, ncand);
+          for (int32_t i = 0; i < nn; i++) {
+            act[(size_t)m * ncols + ncand[i].val] = 1;
+            key[(size_t)m * ncols + ncand[i].val] = (float)ATy[ncand[i].val];
+          }
+        } else
         for (int32_t i = 0; i < ncols; i++) {
           if (ATy[i] > cfg->l1r && i != iC) {
             act[(size_t)m * ncols + i] = 1;
@@ -857,7 +868,7 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
         memset(yhat, 0, sizeof(double) * (size_t)nrows);
       } /* (implicit barrier: the next tile rewrites act / key / uni) */
     }
-    free(x); free(y); free(yhat); free(ATy);
+    free(x); free(y); free(yhat); free(ATy); free(nmark); free(ncand);
   }
   g_learn_seconds = now_seconds() - t_learn0;
   free(key); free(act); free(uni); free(Gm);

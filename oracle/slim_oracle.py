@@ -143,7 +143,8 @@ def tile_work_order(R, col_begin=0, col_end=None):
 
 
 def learn_cd_tile(R, tileP=32, order=None, l1r=1.0, l2r=1.0, optTol=1e-7, maxniters=10000,
-                  nthreads=1, seed=1, binary=False, return_stats=False, tiles=None):
+                  nthreads=1, seed=1, binary=False, return_stats=False, tiles=None, nnbrs=0,
+                  simtype=0):
     """EstimateModelCD in the tile kernel's visiting order (see oracle_learn_cd_tile).
     tiles=(first, count): walk only those tiles of the work list (their position keys the
     visiting order, so a tile of a larger launch can be checked alone)."""
@@ -152,8 +153,8 @@ def learn_cd_tile(R, tileP=32, order=None, l1r=1.0, l2r=1.0, optTol=1e-7, maxnit
     if order is None:
         order = tile_work_order(R)
     order = np.ascontiguousarray(order, dtype=np.int32)
-    cfg = Cfg(l1r, l2r, optTol, maxniters, nthreads, ORDER_PERM, seed, ATY_GRAM, 0, 0, 0, 0,
-              tiles[0] if tiles else 0, tiles[1] if tiles else 0)
+    cfg = Cfg(l1r, l2r, optTol, maxniters, nthreads, ORDER_PERM, seed, ATY_GRAM, 0, nnbrs, simtype,
+              0, tiles[0] if tiles else 0, tiles[1] if tiles else 0)
     ncols = int(ind.max()) + 1 if ind.size else 0
     stats = np.zeros(ncols, dtype=COLSTAT_DTYPE)
     wptr, wind, wval = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_float)()

@@ -322,8 +322,88 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     }
     cluster_barrier();  // every member's partial sums are published
 
-    // -- active sets (estimate.c:433-444): x = 0 for active, -inf for inactive
-    {
+    // -- active sets: x = 0 for active, -inf for inactive
+    if (S.nnbrs > 0) {
+      // FSLIM (estimate.c:424-431, neighbors.c:16-125): the nnbrs columns most similar to the
+      // item among those sharing a user with it, no l1 screen.  The co-rating dot products ARE
+      // the screen sums.  Selection per problem: a 4-pass radix select over the sortable bits
+      // of the similarity finds the nnbrs-th largest value; ties at that value go to the
+      // lower item ids (upstream leaves them undefined; the oracle uses the same rule).
+      uint32_t* const hist = s_bits;       // [P][256]: the user bitmap is dead by now
+      __shared__ uint32_t s_prefix[P], s_want[P];
+      __shared__ float s_cn[P];
+      if (tid < P) {
+        s_prefix[tid] = 0u;
+        s_want[tid] = (uint32_t)S.nnbrs;
+        s_cn[tid] = s_item[tid] >= 0 ? A.cnorm[s_item[tid]] : 0.0f;
+      }
+      __syncthreads();
+      const int64_t n = (int64_t)ncols * P;
+      // similarities (neighbors.c:82-83 cos, :107-109 jac, dotp), -inf for non-candidates
+      for (int64_t idx = tid; idx < n; idx += NT) {
+        const int i = (int)(idx >> LOGP), qq = (int)(idx & (P - 1));
+        const int it = s_item[qq];
+        float a = 0.0f;
+        for (int k = 0; k < K; ++k) a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
+        float sim = kInactive;
+        if (it >= 0 && i != it && a != 0.0f) {
+          const float cn_i = A.cnorm[i];
+          sim = S.simtype == 0 ? a / cn_i : (S.simtype == 1 ? a / ((cn_i + s_cn[qq]) - a) : a);
+        }
+        x[idx] = sim;
+      }
+      // order-preserving map float -> uint32 (-inf maps to 0x007FFFFF: below every finite value)
+      auto keyof = [](const float f) -> uint32_t {
+        const uint32_t b = __float_as_uint(f);
+        return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+      };
+      const uint32_t key_ninf = keyof(kInactive);
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int k = tid; k < P * 256; k += NT) hist[k] = 0u;
+        __syncthreads();
+        for (int64_t idx = tid; idx < n; idx += NT) {
+          const int qq = (int)(idx & (P - 1));
+          const uint32_t key = keyof(x[idx]);
+          if (key == key_ninf) continue;
+          const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+          if ((key & hi_mask) == s_prefix[qq]) atomicAdd(&hist[qq * 256 + ((key >> shift) & 255u)], 1u);
+        }
+        __syncthreads();
+        if (tid < P) {  // walk the digits from the top until `want` entries are covered
+          uint32_t want = s_want[tid], d = 255u;
+          for (;; --d) {
+            const uint32_t c = hist[tid * 256 + d];
+            if (c >= want || d == 0u) break;
+            want -= c;
+          }
+          // fewer candidates than wanted: the walk ends at digit 0 and everything is taken
+          s_prefix[tid] |= d << shift;
+          s_want[tid] = want;
+        }
+        __syncthreads();
+      }
+      // s_prefix = the threshold key T, s_want = how many entries equal to T to keep (ascending
+      // ids).  Wavefront w marks problems w, w + NW, walking the items in order.
+#pragma unroll
+      for (int pp = 0; pp < PPW; ++pp) {
+        const int pq = wave + pp * NW;
+        const uint32_t T = s_prefix[pq];
+        int quota = (int)s_want[pq], na = 0;
+        for (int ib = 0; ib < ncols; ib += 64) {
+          const int i = ib + lane;
+          const uint32_t key = i < ncols ? keyof(x[(int64_t)i * P + pq]) : key_ninf;
+          const bool cand = key != key_ninf;
+          const bool tie = cand && key == T;
+          const uint64_t mt = __ballot(tie);
+          const bool act = cand && (key > T || (tie && __popcll(mt & lane_lt) < quota));
+          quota -= __popcll(mt) < quota ? __popcll(mt) : quota;
+          if (i < ncols) x[(int64_t)i * P + pq] = act ? 0.0f : kInactive;
+          na += __popcll(__ballot(act));
+        }
+        if (lane == 0) s_na[pq] = na;
+      }
+    } else {  // estimate.c:433-444: aTy > l1 (strict), the item itself excluded
       const int64_t n = (int64_t)ncols * P;
       for (int64_t idx = tid; idx < n; idx += NT) {
         const int i = (int)(idx >> LOGP), qq = (int)(idx & (P - 1));
@@ -339,7 +419,8 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     __syncthreads();
 
     // -- warm start (estimate.c:453-464): previous coefficients of active coordinates
-    const bool warm = S.icolptr != nullptr;
+    // (in the FSLIM branch the reference never sets its warm-start flags: a no-op there)
+    const bool warm = S.icolptr != nullptr && S.nnbrs == 0;
     if (warm) {
 #pragma unroll
       for (int pp = 0; pp < PPW; ++pp) {
@@ -480,6 +561,30 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         }
       };
 
+      // The chunk before the last one is parked in LDS (ids, values and the P gathered
+      // residuals of this wavefront's 64 nnz: 8.5 KB per wavefront), the last one stays in
+      // registers: slices of up to two chunks are updated without touching HBM for reads, and
+      // longer ones re-gather one chunk less.
+      float* const park = reinterpret_cast<float*>(s_bits) + wave * (64 * (STEPS + 2));
+      const bool use_park = S.lds_park != 0;
+      auto park_put = [&]() {
+        if (nhere > 0) {
+#pragma unroll
+          for (int j = 0; j < STEPS; ++j) park[j * 64 + lane] = r_c[j];
+        }
+        park[STEPS * 64 + lane] = __int_as_float(idreg);
+        park[(STEPS + 1) * 64 + lane] = vreg;
+      };
+      auto park_get = [&](const int64_t c) {
+        const int64_t left = e - (c + 64 * wave);
+        nhere = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+        idreg = __float_as_int(park[STEPS * 64 + lane]);
+        vreg = park[(STEPS + 1) * 64 + lane];
+        if (nhere > 0) {
+#pragma unroll
+          for (int j = 0; j < STEPS; ++j) r_c[j] = park[j * 64 + lane];
+        }
+      };
       const uint64_t p0 = tick();
       float acc = 0.0f;
       int64_t c0 = s;
@@ -487,6 +592,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         load_ids(c0);
         gather();
         if (mode == 0) acc += dot_block();
+        if (use_park && c0 + 2 * CH >= e) park_put();
       }
       load_ids(c0);  // last chunk: kept in registers for the update
       gather();
@@ -542,9 +648,13 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       const uint64_t p3 = tick();
       if (upd) {
         scatter(d);
-        for (int64_t c = s; c < c0; c += CH) {  // earlier chunks: re-read (L2 / Infinity Cache)
-          load_ids(c);
-          gather();
+        for (int64_t c = s; c < c0; c += CH) {  // earlier chunks: from LDS, or re-gathered
+          if (use_park && c + 2 * CH >= e) {
+            park_get(c);
+          } else {
+            load_ids(c);
+            gather();
+          }
           scatter(d);
         }
       }

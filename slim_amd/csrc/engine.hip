@@ -713,9 +713,6 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int kernel = opt.kernel;
     if (kernel == SLIMGPU_KERNEL_AUTO)
       kernel = lds_need <= 64 * 1024 ? SLIMGPU_KERNEL_WAVE_LDS : SLIMGPU_KERNEL_TILE;
-    // FSLIM (nnbrs > 0) selects its active set per item: one wavefront per item
-    if (opt.nnbrs > 0 && (kernel == SLIMGPU_KERNEL_TILE || kernel == SLIMGPU_KERNEL_TILE16))
-      kernel = SLIMGPU_KERNEL_WAVE_HBM;
     if (kernel == SLIMGPU_KERNEL_WAVE_LDS && lds_need > 160 * 1024) {
       set_error("SLIMGPU_Learn: work vectors do not fit the 160 KiB LDS of a CU");
       return fail(SLIM_ERROR_INPUT);
@@ -776,8 +773,12 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int wg_slots = m->num_cus * (16 / tileNW);
     if (use_tile) {
       int per_cu = 0;
+      const size_t worst_lds = std::max<size_t>(kBitmapBytes, (size_t)tileNW * 64 * ((size_t)tileP + 2) * sizeof(float));
+      if (worst_lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)worst_lds));
       HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn),
-                                                           64 * tileNW, kBitmapBytes));
+                                                           64 * tileNW, worst_lds));
       if (per_cu < 1) {
         set_error("SLIMGPU_Learn: the tile kernel does not fit a compute unit of this device");
         return fail(SLIM_ERROR);
@@ -897,9 +898,21 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       bm_shift = 0;
       while (((range >> bm_shift) + 31) / 32 * 4 > kBitmapBytes) ++bm_shift;
       bm_words = (int)(((range >> bm_shift) + 1 + 31) / 32);
+      if (opt.nnbrs > 0) bm_words = std::max(bm_words, tileP * 256);  // FSLIM's select histograms
     };
+    // dynamic LDS of a tile workgroup: the user bitmap of the screen pass (FSLIM: the select
+    // histograms), reused during the sweeps as the parking area of one chunk per wavefront
+    // (64 nnz x (P residuals + id + value) = 8.5 KB at P = 32)
+    bool lds_park = use_tile;
+    if (const char* e = std::getenv("SLIM_GPU_LDS_PARK")) lds_park = lds_park && std::atoi(e) != 0;
+    size_t tile_lds = 0;
     if (use_tile) {
       alloc_tiles();
+      const size_t park_bytes = (size_t)tileNW * 64 * ((size_t)tileP + 2) * sizeof(float);
+      tile_lds = std::max(sizeof(uint32_t) * (size_t)bm_words, lds_park ? park_bytes : (size_t)0);
+      if (tile_lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
     } else if (!use_lds) {
       d_slab = ws_get<float>(m->ws_slab, vec_floats * (size_t)nwaves);
     }
@@ -1015,6 +1028,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.csplit = use_tile ? m->d_csplit[cluster_lg] : nullptr;
       S.mailbox = d_mailbox;
       S.exact_gram = (m->exact_gram || std::getenv("SLIM_GPU_EXACT_GRAM")) ? 1 : 0;
+      S.lds_park = lds_park ? 1 : 0;
       S.atypart = d_part;
       S.bm_shift = bm_shift;
       S.bm_words = bm_words;
@@ -1068,8 +1082,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       }
       HIP_TRY(hipEventRecord(ev0, stream));
       hipLaunchKernelGGL(fn, dim3(launch_now), dim3(use_tile ? 64 * tileNW : 64),
-                         use_lds ? lds_need : (use_tile ? sizeof(uint32_t) * (size_t)bm_words : 0),
-                         stream, A, S);
+                         use_lds ? lds_need : (use_tile ? tile_lds : 0), stream, A, S);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(ev1, stream));
 

@@ -617,8 +617,28 @@ def test_fslim_more_neighbours_than_candidates(ml100k, ml_dev):
     assert maxdiff(big, big_o) <= 2e-5
     W_hbm, _ = ml_dev.learn(seed=1, nnbrs=50, simtype=0, kernel=KERNEL_WAVE_HBM)
     assert maxdiff(W_hbm, W) == 0.0
-    W_tile, st_t = ml_dev.learn(seed=1, nnbrs=50, simtype=0, kernel=KERNEL_TILE)  # rerouted
-    assert st_t["kernel"] == KERNEL_WAVE_HBM and maxdiff(W_tile, W) == 0.0
+
+
+@pytest.mark.parametrize("simtype", [0, 1, 2])
+@pytest.mark.parametrize("cluster", [1, 4])
+def test_fslim_tile_kernel_matches_oracle(ml100k, ml_dev, automotive, simtype, cluster):
+    """FSLIM on the large-matrix path.  The tile kernel selects every problem's
+    neighbours from the screen sums (radix select, ties to the lower id) and the oracle walks
+    the same tiles in the same order with FindColumnNeighbors' lists: same neighbour counts,
+    same W; also with more neighbours asked for than candidates exist."""
+    for R, nnbrs in ((ml100k[0], 40), (sp.csr_matrix(automotive[0]), 10), (ml100k[0], 5000)):
+        m = DeviceMatrix.from_scipy(R)
+        W, st = m.learn(seed=2, nnbrs=nnbrs, simtype=simtype, kernel=KERNEL_TILE, cluster=cluster,
+                        niters=200)
+        assert st["kernel"] == KERNEL_TILE
+        cs = m.column_stats()
+        Wo, so, _, _ = O.learn_cd_tile(R, tileP=32, maxniters=200, seed=2, nthreads=8, nnbrs=nnbrs,
+                                       simtype=simtype, return_stats=True)
+        n = R.shape[1]
+        assert np.array_equal(cs.nacols[:n], so["nacols"][:n])
+        assert cs.nacols.max() <= nnbrs
+        assert maxdiff(W, Wo) <= 2e-5 and pattern_diff(W, Wo) <= 4
+        m.close()
 
 
 def test_output_arena_overflow_is_recovered(ml100k, ml_gpu, monkeypatch):

@@ -249,3 +249,31 @@ def test_one_process_per_gpu_driver_on_device(ml100k, tmp_path):
         assert abs(w0 - w1).nnz == 0 and maxdiff(w0, want) == 0.0 and w0.nnz == want.nnz
         t = np.load(str(tmp_path / (partition + "0.npy")))
         assert t[0] == R.shape[1] and t[1] == want.nnz
+
+
+@pytest.mark.timeout(420, method="thread")
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_multi_rank_branch(scaling):
+    """bench.py's own world > 1 path (shards per rank, barrier + max-over-ranks timing, gather of
+    the learned columns on rank 0), launched the way the driver launches it.  On a one-GPU box
+    the two ranks share the device and the collectives run over gloo; with two devices, RCCL."""
+    import json
+    import socket
+    import torch
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "ml100k",
+           "--backend", backend, "--scaling", scaling, "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == scaling
+    assert out["value"] > 0 and out["unit"] == "item-columns/s"
+    assert out["config"]["columns_per_step"] == 1683
+    assert out["roofline"]["nnzW"] > 0
