@@ -237,6 +237,61 @@ static double now_seconds(void) {
 
 static void fkv_sortd_stable(fkv_t *a, int64_t n);
 
+/* CreateTrainingMatrix (setup.c:109-135): column view + norms of the caller's CSR.  With the
+ * cache switched on (oracle_cache_setup(1): bench.py's CPU leg, which calls the oracle several
+ * times on one 1e9-nnz matrix) the view of the last matrix is kept and reused while the caller
+ * passes the same rowind array; the caller owns that guarantee and clears the cache afterwards. */
+typedef struct {
+  int64_t *colptr;
+  int32_t *colind;
+  float *colval;
+  float *cnorms;
+} colview_t;
+static int g_cache_on = 0;
+static struct {
+  const int32_t *rowind;
+  const float *rowval;
+  int64_t nnz;
+  int32_t nrows, ncols;
+  colview_t v;
+} g_cache = {0};
+
+static void colview_free(colview_t *v) {
+  free(v->colptr); free(v->colind); free(v->colval); free(v->cnorms);
+  memset(v, 0, sizeof(*v));
+}
+void oracle_cache_setup(int32_t on) {
+  g_cache_on = on;
+  if (!on && g_cache.v.colptr) {
+    colview_free(&g_cache.v);
+    memset(&g_cache, 0, sizeof(g_cache));
+  }
+}
+static colview_t colview_get(int32_t nrows, int32_t ncols, const int64_t *rowptr,
+                             const int32_t *rowind, const float *rowval) {
+  const int64_t nnz = rowptr[nrows];
+  if (g_cache_on && g_cache.v.colptr && g_cache.rowind == rowind && g_cache.rowval == rowval &&
+      g_cache.nnz == nnz && g_cache.nrows == nrows && g_cache.ncols == ncols)
+    return g_cache.v;
+  colview_t v;
+  v.colptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)ncols + 1));
+  v.colind = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+  v.colval = rowval ? (float *)malloc(sizeof(float) * (size_t)(nnz ? nnz : 1)) : NULL;
+  v.cnorms = (float *)malloc(sizeof(float) * (size_t)ncols);
+  oracle_transpose(nrows, ncols, rowptr, rowind, rowval, v.colptr, v.colind, v.colval);
+  oracle_col_norms(ncols, v.colptr, v.colval, v.cnorms);
+  if (g_cache_on) {
+    if (g_cache.v.colptr) colview_free(&g_cache.v);
+    g_cache.rowind = rowind; g_cache.rowval = rowval; g_cache.nnz = nnz;
+    g_cache.nrows = nrows; g_cache.ncols = ncols; g_cache.v = v;
+  }
+  return v;
+}
+static void colview_put(colview_t *v) {
+  if (g_cache_on && g_cache.v.colptr == v->colptr) return; /* kept */
+  colview_free(v);
+}
+
 /* neighbors.c:16-125 FindColumnNeighbors: candidates = items co-rated with iC,
  * similarity accumulated in FLOAT over (users of iC ascending, row order)
  * (neighbors.c:46-60), cos: / cnorm[k] (:82-83), jac: / (cnorm[k] + cnorm[iC] - key)
@@ -441,13 +496,11 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
   if (ncols <= 0) return -1;
 
   /* CreateTrainingMatrix: column view + norms (setup.c:128-132) */
-  int64_t *colptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)ncols + 1));
-  int32_t *colind = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
-  float *colval =
-      rowval ? (float *)malloc(sizeof(float) * (size_t)(nnz ? nnz : 1)) : NULL;
-  float *cnorms = (float *)malloc(sizeof(float) * (size_t)ncols);
-  oracle_transpose(nrows, ncols, rowptr, rowind, rowval, colptr, colind, colval);
-  oracle_col_norms(ncols, colptr, colval, cnorms);
+  colview_t cvw = colview_get(nrows, ncols, rowptr, rowind, rowval);
+  int64_t *colptr = cvw.colptr;
+  int32_t *colind = cvw.colind;
+  float *colval = cvw.colval;
+  float *cnorms = cvw.cnorms;
   cview_t A = {colptr, colind, colval, cnorms};
 
   int32_t *nnzs = (int32_t *)calloc((size_t)ncols, sizeof(int32_t));
@@ -676,10 +729,7 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
   }
   free(lists);
   free(nnzs);
-  free(colptr);
-  free(colind);
-  free(colval);
-  free(cnorms);
+  colview_put(&cvw);
   *r_colptr = wptr;
   *r_colind = wind;
   *r_colval = wval;
@@ -709,13 +759,11 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
   const int64_t nnz = rowptr[nrows];
   const int32_t ncols = oracle_ncols(nnz, rowind);
   if (ncols <= 0 || tileP <= 0) return -1;
-  int64_t *colptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)ncols + 1));
-  int32_t *colind = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
-  float *colval =
-      rowval ? (float *)malloc(sizeof(float) * (size_t)(nnz ? nnz : 1)) : NULL;
-  float *cnorms = (float *)malloc(sizeof(float) * (size_t)ncols);
-  oracle_transpose(nrows, ncols, rowptr, rowind, rowval, colptr, colind, colval);
-  oracle_col_norms(ncols, colptr, colval, cnorms);
+  colview_t cvw = colview_get(nrows, ncols, rowptr, rowind, rowval);
+  int64_t *colptr = cvw.colptr;
+  int32_t *colind = cvw.colind;
+  float *colval = cvw.colval;
+  float *cnorms = cvw.cnorms;
   cview_t A = {colptr, colind, colval, cnorms};
   int32_t *nnzs = (int32_t *)calloc((size_t)ncols, sizeof(int32_t));
   fkv_t **lists = (fkv_t **)calloc((size_t)ncols, sizeof(fkv_t *));
@@ -888,7 +936,8 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
     wptr[c + 1] = tnnz;
     free(lists[c]);
   }
-  free(lists); free(nnzs); free(colptr); free(colind); free(colval); free(cnorms);
+  free(lists); free(nnzs);
+  colview_put(&cvw);
   *r_colptr = wptr;
   *r_colind = wind;
   *r_colval = wval;

@@ -70,7 +70,7 @@ def _p(a, t):
 
 
 def _csr_arrays(R, binary=False):
-    R = sp.csr_matrix(R)
+    R = sp.csr_matrix(R)   # (no copy for a CSR input: repeated calls pass the same index array)
     ptr = np.ascontiguousarray(R.indptr, dtype=np.int64)
     ind = np.ascontiguousarray(R.indices, dtype=np.int32)
     val = None if binary else np.ascontiguousarray(R.data, dtype=np.float32)
@@ -241,6 +241,12 @@ def perm_index(p, n, key):
 
 def perm_key(seed, item, sweep):
     return int(lib().oracle_perm_key(seed, item, sweep))
+
+
+def cache_setup(on):
+    """Keep the column view (transpose + norms) of the last matrix across calls while the SAME
+    index array is passed (bench.py's CPU leg on a 1e9-nnz matrix); cache_setup(False) frees it."""
+    lib().oracle_cache_setup(C.c_int32(1 if on else 0))
 
 
 def learn_seconds():

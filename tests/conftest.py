@@ -4,6 +4,17 @@ import sys
 import numpy as np
 import pytest
 
+# torch ships its own HIP runtime; it must initialise BEFORE libslim.so (linked against the
+# system ROCm) is loaded into this process, or torch finds "no ROCm-capable device" later
+# (the full-size tests generate their matrices on the GPU with torch).  bench.py imports in the
+# same order.
+try:
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+except Exception:  # pragma: no cover - torch is plumbing here; CPU tests do not need it
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:

@@ -66,6 +66,7 @@ def test_c4_full_size_tiles_match_oracle_in_tile_order():
     bench.py's cpu_baseline samples, and -- so that the heavy phase and clusters of 16 are in
     play -- the same tiles once more as a two-tile launch with a heavy phase."""
     mat, R = _stage("c4")
+    O.cache_setup(True)           # one transpose of R for the oracle calls of this test
     threads = min(32, O.max_threads())
     tiles = _batch_tiles(mat, 0, 8192)
     rng = np.random.default_rng(1)
@@ -83,6 +84,7 @@ def test_c4_full_size_tiles_match_oracle_in_tile_order():
     Wo2 = O.learn_cd_tile(R, tileP=32, order=order, maxniters=10000, seed=1, nthreads=threads,
                           binary=True, l1r=1.0, l2r=1.0, optTol=1e-7)
     assert maxdiff(W2[:, both], Wo2[:, both]) <= 2e-5
+    O.cache_setup(False)
     mat.close()
 
 
