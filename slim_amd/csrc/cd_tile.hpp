@@ -62,6 +62,13 @@
 namespace slimamd {
 
 constexpr int kTileNW = 16;  // wavefronts per workgroup (default geometry)
+// experiments (A/B through -D at build time; the defaults are what measured best)
+#ifndef SLIM_TILE_ID_PIPE
+#define SLIM_TILE_ID_PIPE 1   // request the ids of chunk c+1 before gathering chunk c
+#endif
+#ifndef SLIM_TILE_PF_ALL
+#define SLIM_TILE_PF_ALL 0    // next visit's first ids requested during the exchange in every
+#endif                        // phase (1) or in the heavy phase only (0)
 constexpr int kTileKMax = 32;  // largest cluster (workgroups sharing one tile)
 constexpr float kInactive = -__builtin_huge_valf();
 __device__ __forceinline__ bool tile_active(float xv) { return xv > -3.0e38f; }
@@ -84,7 +91,7 @@ __device__ __forceinline__ tile_gran_t gran_load(const tile_gran_t* p) {
 // phase is a template parameter so that the cluster geometry stays a function of kernel
 // arguments (re-derivable, no live registers across the visit loop).  Returns false when
 // the launch was aborted.
-template <int P, bool HAS_VAL, bool PROFILE, int NW, bool HI>
+template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM, bool PARK, bool HI>
 __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& S, uint32_t& epoch) {
   constexpr int NT = 64 * NW;  // threads per workgroup
   constexpr int SL = 64 / P;       // users per wavefront step (lane groups)
@@ -323,7 +330,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     cluster_barrier();  // every member's partial sums are published
 
     // -- active sets: x = 0 for active, -inf for inactive
-    if (S.nnbrs > 0) {
+    if (FSLIM) {
       // FSLIM (estimate.c:424-431, neighbors.c:16-125): the nnbrs columns most similar to the
       // item among those sharing a user with it, no l1 screen.  The co-rating dot products ARE
       // the screen sums.  Selection per problem: a 4-pass radix select over the sortable bits
@@ -420,7 +427,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 
     // -- warm start (estimate.c:453-464): previous coefficients of active coordinates
     // (in the FSLIM branch the reference never sets its warm-start flags: a no-op there)
-    const bool warm = S.icolptr != nullptr && S.nnbrs == 0;
+    const bool warm = S.icolptr != nullptr && !FSLIM;
     if (warm) {
 #pragma unroll
       for (int pp = 0; pp < PPW; ++pp) {
@@ -514,7 +521,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         const int64_t left = e - b0;
         nhere = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
         const bool ok = lane < nhere;
-        if (HI && c0 == pf_here) {  // requested during the previous visit
+        if ((HI || SLIM_TILE_PF_ALL) && c0 == pf_here) {  // requested during the previous visit
           idreg = pf_id;
           vreg = pf_v;
           pf_here = -1;  // (pf_id is reused for the next visit before this block is re-read)
@@ -566,7 +573,6 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       // registers: slices of up to two chunks are updated without touching HBM for reads, and
       // longer ones re-gather one chunk less.
       float* const park = reinterpret_cast<float*>(s_bits) + wave * (64 * (STEPS + 2));
-      const bool use_park = S.lds_park != 0;
       auto park_put = [&]() {
         if (nhere > 0) {
 #pragma unroll
@@ -588,21 +594,41 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       const uint64_t p0 = tick();
       float acc = 0.0f;
       int64_t c0 = s;
+#if SLIM_TILE_ID_PIPE
+      // the ids (and values) of chunk c+1 are requested before chunk c is gathered, so a chunk's
+      // gathers never wait for an id load issued after the previous chunk's dot
+      load_ids(c0);
+      for (; c0 + CH < e; c0 += CH) {
+        const int64_t b1 = c0 + CH + 64 * wave;
+        const int64_t left1 = e - b1;
+        const int n1 = left1 <= 0 ? 0 : (left1 < 64 ? (int)left1 : 64);
+        const int id_nx = lane < n1 ? ci[b1 + lane] - ubase : 0;
+        const float v_nx = lane < n1 ? (HAS_VAL ? cv[b1 + lane] : 1.0f) : 0.0f;
+        gather();
+        if (mode == 0) acc += dot_block();
+        if (PARK && c0 + 2 * CH >= e) park_put();
+        idreg = id_nx;
+        vreg = v_nx;
+        nhere = n1;
+      }
+      gather();  // last chunk: kept in registers for the update
+#else
       for (; c0 + CH < e; c0 += CH) {
         load_ids(c0);
         gather();
         if (mode == 0) acc += dot_block();
-        if (use_park && c0 + 2 * CH >= e) park_put();
+        if (PARK && c0 + 2 * CH >= e) park_put();
       }
       load_ids(c0);  // last chunk: kept in registers for the update
       gather();
+#endif
       // (sn_v / nn_v are still in flight when the visit starts: made uniform only here.)  The
       // loads are unconditional instructions with a clamped address -- lanes past the slice hold
       // garbage that load_ids never looks at -- so that exactly one (two with values) load is in
       // flight behind the gather on every path and the dot below waits for the gather only
       // (s_waitcnt vmcnt(1|2)); a load under a condition makes the count path-dependent and the
       // compiler drains the queue instead.
-      if (HI && mode == 0) {
+      if ((HI || SLIM_TILE_PF_ALL) && mode == 0) {
         const int64_t sn = uni(sn_v);
         const int nn = uni(nn_v);
         int64_t jj = sn + 64 * wave + lane;
@@ -649,7 +675,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       if (upd) {
         scatter(d);
         for (int64_t c = s; c < c0; c += CH) {  // earlier chunks: from LDS, or re-gathered
-          if (use_park && c + 2 * CH >= e) {
+          if (PARK && c + 2 * CH >= e) {
             park_get(c);
           } else {
             load_ids(c);
@@ -835,16 +861,21 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 // -- gather / barrier / cluster exchange / write-back -- then overlap).
 // (16 wavefronts per CU either way: the second launch bound, 4 waves per SIMD, caps the
 // kernel at 128 VGPRs)
-template <int P, bool HAS_VAL, bool PROFILE, int NW>
+// FSLIM (neighbour selection instead of the l1 screen) and PARK (second-to-last chunk of a visit
+// kept in LDS) are separate instantiations: the visit loop sits at the 128-VGPR cap, and code
+// that merely exists in the same kernel costs it 5 % (the FSLIM block) to 10-19 % (parking) --
+// measured same-box on C4 (profiles/r02/ab_variants.txt); parking pays only where nearly every
+// visit updates and slices are long (C5: +7 % net).
+template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM = false, bool PARK = false>
 __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
   uint32_t epoch = 0;
   // heavy phase first: whole clusters of S.cluster_hi only (S.cluster divides S.cluster_hi,
   // so the workgroups of a big cluster regroup into whole small ones afterwards)
   if (S.nheavy > 0 && (int)blockIdx.x < ((int)gridDim.x / S.cluster_hi) * S.cluster_hi) {
-    if (!tile_phase<P, HAS_VAL, PROFILE, NW, true>(A, S, epoch)) return;
+    if (!tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, PARK, true>(A, S, epoch)) return;
     __syncthreads();
   }
-  tile_phase<P, HAS_VAL, PROFILE, NW, false>(A, S, epoch);
+  tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, PARK, false>(A, S, epoch);
 }
 
 }  // namespace slimamd

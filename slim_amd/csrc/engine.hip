@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,6 +36,7 @@ struct slimgpu_matrix {
   bool binary = false;
   bool owns_csr = false;
   bool exact_gram = false;  // ratings are not small integers: aTy sums formed in a fixed order
+  double last_update_share = -1;  // U / D of the previous solve (-1: none yet)
   // CSR
   int64_t* d_rowptr = nullptr;
   int32_t* d_rowind = nullptr;
@@ -731,6 +733,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       use_tile = false;  // > 67M users: fall back to one wavefront per item
       kernel = SLIMGPU_KERNEL_WAVE_HBM;
     }
+    if (use_tile && tileP == 16 && opt.nnbrs > 0) {  // FSLIM exists for 32-wide tiles only
+      use_tile = false;
+      kernel = SLIMGPU_KERNEL_WAVE_HBM;
+    }
     if (use_tile) kernel = tileP == 32 ? SLIMGPU_KERNEL_TILE : SLIMGPU_KERNEL_TILE16;
     const char* trace_env = std::getenv("SLIM_GPU_TRACE");
     const int trace_level = trace_env ? std::atoi(trace_env) : 0;
@@ -744,10 +750,28 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int tileNW = (nwork + tileP - 1) / tileP >= 2 * m->num_cus ? 8 : 16;
     // (four 4-wavefront workgroups per CU were measured too: no gain, even on columns of ~900 nnz)
     if (const char* e = std::getenv("SLIM_GPU_TILE_NW")) tileNW = std::atoi(e) == 16 ? 16 : 8;
+    // LDS parking of a visit's second-to-last chunk (a separate instantiation: it costs the
+    // visit loop 10-19 % and saves one chunk's re-gather per UPDATING visit).  It pays where
+    // nearly every visit of a tile updates some coefficient and slices span several chunks:
+    // C5 (+7 %), not C4 (-10 %).  The update share of the previous solve of this matrix decides;
+    // before the first solve, the expected density of W (a few thousand entries per column).
+    bool lds_park = false;
+    if (use_tile && tileP == 32 && opt.nnbrs == 0 && trace_level < 2) {
+      const double dens = m->last_update_share >= 0 ? m->last_update_share
+                                                    : std::min(1.0, 3000.0 / std::max(ncols, 1));
+      const double tile_upd = 1.0 - std::pow(1.0 - dens, 32.0);
+      const double slice = (double)m->nnz / std::max(ncols, 1) / 8.0;  // at a typical K
+      lds_park = tile_upd > 0.9 && slice >= 2.0 * 64 * tileNW;
+      if (const char* e = std::getenv("SLIM_GPU_LDS_PARK")) lds_park = std::atoi(e) != 0;
+    }
     if (use_tile) {
       const bool prof = trace_level >= 2;
       const bool val = !m->binary;
-      if (tileP == 32)
+      if (tileP == 32 && opt.nnbrs > 0)
+        fn = tileNW == 16 ? tile_kernel_p32_nw16_extra(val, true) : tile_kernel_p32_nw8_extra(val, true);
+      else if (tileP == 32 && lds_park)
+        fn = tileNW == 16 ? tile_kernel_p32_nw16_extra(val, false) : tile_kernel_p32_nw8_extra(val, false);
+      else if (tileP == 32)
         fn = tileNW == 16 ? tile_kernel_p32_nw16(val, prof) : tile_kernel_p32_nw8(val, prof);
       else
         fn = tileNW == 16 ? tile_kernel_p16_nw16(val, prof) : tile_kernel_p16_nw8(val, prof);
@@ -773,7 +797,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int wg_slots = m->num_cus * (16 / tileNW);
     if (use_tile) {
       int per_cu = 0;
-      const size_t worst_lds = std::max<size_t>(kBitmapBytes, (size_t)tileNW * 64 * ((size_t)tileP + 2) * sizeof(float));
+      const size_t worst_lds = std::max<size_t>(
+          kBitmapBytes, lds_park ? (size_t)tileNW * 64 * ((size_t)tileP + 2) * sizeof(float) : (size_t)0);
       if (worst_lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)worst_lds));
@@ -903,8 +928,6 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     // dynamic LDS of a tile workgroup: the user bitmap of the screen pass (FSLIM: the select
     // histograms), reused during the sweeps as the parking area of one chunk per wavefront
     // (64 nnz x (P residuals + id + value) = 8.5 KB at P = 32)
-    bool lds_park = use_tile;
-    if (const char* e = std::getenv("SLIM_GPU_LDS_PARK")) lds_park = lds_park && std::atoi(e) != 0;
     size_t tile_lds = 0;
     if (use_tile) {
       alloc_tiles();
@@ -1258,6 +1281,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       st.objval += h_obj[c];
     }
     st.nnzW = tnnz;
+    if (st.D > 0) m->last_update_share = (double)st.U / (double)st.D;
     st.alg_bytes = m->binary
                        ? 4.0 * st.G + 8.0 * st.D + 4.0 * st.U + 8.0 * st.nnzW
                        : 8.0 * st.G + 12.0 * st.D + 4.0 * st.U + 8.0 * st.nnzW;

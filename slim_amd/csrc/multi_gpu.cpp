@@ -54,7 +54,9 @@ bool resolve_devices(const LearnOptions& opt, std::vector<int>* out, std::string
     if (!out->empty()) return true;
   }
   if (opt.ngpus <= 1) {
-    out->push_back(opt.device);  // -1: current device (pick_device)
+    int dev = opt.device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;  // -1: the current device
+    out->push_back(dev);
     return true;
   }
   if (opt.ngpus > count) {

@@ -1,6 +1,7 @@
-// tile_inst.hpp -- one translation unit per (tile width, workgroup size) of cd_tile_kernel,
-// so that the four geometries compile side by side (`make -j`); engine.hip picks the
-// instantiation through tile_kernel().
+// tile_inst.hpp -- the instantiations of cd_tile_kernel, a few per translation unit so that
+// they compile side by side (`make -j`); engine.hip picks one through tile_kernel().
+//   base : <P, HAS_VAL, PROFILE, NW>                       P in {32, 16}, NW in {16, 8}
+//   extra: <32, HAS_VAL, false, NW, FSLIM> and <32, HAS_VAL, false, NW, false, PARK>
 #pragma once
 #include "cd_tile.hpp"
 
@@ -12,6 +13,9 @@ KernelFn tile_kernel_p32_nw16(bool has_val, bool profile);
 KernelFn tile_kernel_p32_nw8(bool has_val, bool profile);
 KernelFn tile_kernel_p16_nw16(bool has_val, bool profile);
 KernelFn tile_kernel_p16_nw8(bool has_val, bool profile);
+// P = 32 only: neighbour selection (FSLIM) / LDS parking of the second-to-last chunk
+KernelFn tile_kernel_p32_nw16_extra(bool has_val, bool fslim);
+KernelFn tile_kernel_p32_nw8_extra(bool has_val, bool fslim);
 
 #define SLIM_TILE_INSTANTIATE(NAME, PP, NWW)                                        \
   KernelFn NAME(bool has_val, bool profile) {                                        \
@@ -19,6 +23,14 @@ KernelFn tile_kernel_p16_nw8(bool has_val, bool profile);
                               : cd_tile_kernel<PP, true, false, NWW>)                \
                    : (profile ? cd_tile_kernel<PP, false, true, NWW>                 \
                               : cd_tile_kernel<PP, false, false, NWW>);              \
+  }
+
+#define SLIM_TILE_INSTANTIATE_EXTRA(NAME, NWW)                                             \
+  KernelFn NAME(bool has_val, bool fslim) {                                                \
+    return has_val ? (fslim ? cd_tile_kernel<32, true, false, NWW, true, false>            \
+                            : cd_tile_kernel<32, true, false, NWW, false, true>)           \
+                   : (fslim ? cd_tile_kernel<32, false, false, NWW, true, false>           \
+                            : cd_tile_kernel<32, false, false, NWW, false, true>);         \
   }
 
 }  // namespace slimamd
