@@ -91,7 +91,7 @@ __device__ __forceinline__ tile_gran_t gran_load(const tile_gran_t* p) {
 // phase is a template parameter so that the cluster geometry stays a function of kernel
 // arguments (re-derivable, no live registers across the visit loop).  Returns false when
 // the launch was aborted.
-template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM, bool PARK, bool HI>
+template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM, bool PARK, bool WIDE, bool HI>
 __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& S, uint32_t& epoch) {
   constexpr int NT = 64 * NW;  // threads per workgroup
   constexpr int SL = 64 / P;       // users per wavefront step (lane groups)
@@ -503,7 +503,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     int pf_id = 0;
     float pf_v = 0.0f;
     int64_t pf_at = -1;  // slice start the prefetched block belongs to (-1: none)
-    auto visit = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
+    auto visit_std = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
                      const float xi, const float cn, const float sq, const bool live, float& dlt,
                      const int mode, const int64_t sn_v, const int nn_v) {
       int64_t pf_here = pf_at;  // valid for the first load of the first block only
@@ -699,6 +699,167 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       }
     };
 
+    // The WIDE form of a visit (see cd_tile_kernel): the same arithmetic, two blocks per
+    // wavefront, the chunk before the current one kept in registers.
+    struct Blk {
+      int id;
+      float v;
+      int n;
+      float r[STEPS];
+    };
+    auto visit_wide = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
+                          const float xi, const float cn, const float sq, const bool live,
+                          float& dlt, const int mode, const int64_t, const int) {
+      const bool part = live && tile_active(xi);
+      if (!__any(part)) return;
+      constexpr int64_t CH = 128 * NW;  // nnz per workgroup chunk
+      auto ids = [&](Blk& b, const int64_t b0) {
+        const int64_t left = e - b0;
+        b.n = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+        const bool ok = lane < b.n;
+        b.id = ok ? ci[b0 + lane] - ubase : 0;
+        b.v = ok ? (HAS_VAL ? cv[b0 + lane] : 1.0f) : 0.0f;
+      };
+      auto gather = [&](Blk& b) {
+        if (b.n > 0) {
+#pragma unroll
+          for (int j = 0; j < STEPS; ++j) {
+            const int src = j * SL + slot;
+            const int u = __shfl(b.id, src);
+            b.r[j] = 0.0f;
+            if (src < b.n)
+              b.r[j] = *reinterpret_cast<const float*>(rb + (((uint32_t)u * (uint32_t)(4 * P)) | qoff));
+          }
+        }
+      };
+      auto settle = [&](Blk& b) {
+        if (b.n > 0) {
+#pragma unroll
+          for (int j = 0; j < STEPS; ++j) pin(b.r[j]);
+        }
+      };
+      auto dot_blk = [&](const Blk& b) -> float {
+        float a = 0.0f;
+        if (b.n > 0) {
+#pragma unroll
+          for (int j = 0; j < STEPS; ++j) a += __shfl(b.v, j * SL + slot) * b.r[j];
+        }
+        return a;
+      };
+      auto scatter = [&](const Blk& b, const float d) {
+        if (b.n > 0) {
+#pragma unroll
+          for (int j = 0; j < STEPS; ++j) {
+            const int src = j * SL + slot;
+            const int u = __shfl(b.id, src);
+            const float v = __shfl(b.v, src);
+            if (src < b.n)
+              *reinterpret_cast<float*>(rbw + (((uint32_t)u * (uint32_t)(4 * P)) | qoff)) =
+                  b.r[j] - d * v;
+          }
+        }
+      };
+      const uint64_t p0 = tick();
+      Blk a0, a1, k0, k1;  // current chunk, previous chunk
+      k0.n = k1.n = 0;
+      k0.id = k1.id = 0;
+      k0.v = k1.v = 0.0f;
+      bool kept = false;
+      float acc = 0.0f;
+      int64_t c0 = s;
+      ids(a0, c0 + 128 * wave);
+      ids(a1, c0 + 128 * wave + 64);
+      for (; c0 + CH < e; c0 += CH) {
+        Blk n0, n1;  // (only id / v / n are used: the next chunk's ids go out first)
+        ids(n0, c0 + CH + 128 * wave);
+        ids(n1, c0 + CH + 128 * wave + 64);
+        gather(a0);
+        gather(a1);
+        settle(a0);
+        settle(a1);
+        if (mode == 0) acc += dot_blk(a0) + dot_blk(a1);
+        k0 = a0;
+        k1 = a1;
+        kept = true;
+        a0.id = n0.id; a0.v = n0.v; a0.n = n0.n;
+        a1.id = n1.id; a1.v = n1.v; a1.n = n1.n;
+      }
+      gather(a0);
+      gather(a1);
+      settle(a0);
+      settle(a1);
+      const uint64_t p1 = tick();
+
+      float d = 0.0f, nx = xi;
+      uint64_t p2 = p1;
+      if (mode == 0) {
+        acc += dot_blk(a0) + dot_blk(a1);
+        if (SL == 4) acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (slot == 0) s_part[buf][wave][q] = acc;
+        __syncthreads();
+        float dot = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dot += s_part[buf][w][q];
+        buf ^= 1;
+        dot = cluster_sum(dot);
+        p2 = tick();
+        const float xeff = (xi > kEps || xi < -kEps) ? xi : 0.0f;
+        const float num = dot + xeff * sq;
+        nx = num > l1 ? (num - l1) / (cn * cn + l2) : 0.0f;
+        const float neff = (nx > kEps || nx < -kEps) ? nx : 0.0f;
+        d = neff - xeff;
+        if (!part) {
+          d = 0.0f;
+          nx = xi;
+        } else {
+          D_q += len;
+          dlt += (nx - xi) * (nx - xi);
+          if (d != 0.0f) U_q += len;
+        }
+      } else {
+        d = (part && (xi > kEps || xi < -kEps)) ? xi : 0.0f;
+      }
+      const bool upd = __any(d != 0.0f);
+      const bool xch = mode == 0 && __any(part && nx != xi);
+      const uint64_t p3 = tick();
+      if (upd) {
+        scatter(a0, d);
+        scatter(a1, d);
+        if (kept) {
+          scatter(k0, d);
+          scatter(k1, d);
+        }
+        for (int64_t c = s; c + CH < c0; c += CH) {  // chunks before the kept one: re-gathered
+          ids(a0, c + 128 * wave);
+          ids(a1, c + 128 * wave + 64);
+          gather(a0);
+          gather(a1);
+          scatter(a0, d);
+          scatter(a1, d);
+        }
+      }
+      if (xch && wave == 0 && slot == 0 && part && nx != xi) x[(int64_t)i * P + q] = nx;
+      const uint64_t p4 = PROFILE ? clock64() : 0;
+      if (upd || xch) __syncthreads();
+      if (PROFILE) {
+        const uint64_t p5 = clock64();
+        prof[0] += p1 - p0;
+        prof[1] += p2 - p1;
+        prof[2] += p3 - p2;
+        prof[3] += p4 - p3;
+        prof[4] += p5 - p4;
+        prof[5] += 1;
+        prof[6] += upd ? 1 : 0;
+      }
+    };
+    auto visit = [&](auto... args) {
+      if constexpr (WIDE)
+        visit_wide(args...);
+      else
+        visit_std(args...);
+    };
+
     const uint64_t t_setup = wall_clock64();
     if (warm) {
       float unused = 0.0f;
@@ -866,16 +1027,21 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 // that merely exists in the same kernel costs it 5 % (the FSLIM block) to 10-19 % (parking) --
 // measured same-box on C4 (profiles/r02/ab_variants.txt); parking pays only where nearly every
 // visit updates and slices are long (C5: +7 % net).
-template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM = false, bool PARK = false>
-__global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
+// WIDE: 8 wavefronts, ONE workgroup per CU, two 64-nnz blocks per wavefront and chunk -- 2 waves
+// per SIMD leave 256 VGPRs each (no spills), enough to hold the previous chunk of a visit in
+// registers next to the current one: slices of up to two 1024-nnz chunks update without
+// re-gathering, with the same number of line requests in flight per CU as 16 x 1 block.
+template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM = false, bool PARK = false,
+          bool WIDE = false>
+__global__ __launch_bounds__(64 * NW, WIDE ? 2 : 4) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
   uint32_t epoch = 0;
   // heavy phase first: whole clusters of S.cluster_hi only (S.cluster divides S.cluster_hi,
   // so the workgroups of a big cluster regroup into whole small ones afterwards)
   if (S.nheavy > 0 && (int)blockIdx.x < ((int)gridDim.x / S.cluster_hi) * S.cluster_hi) {
-    if (!tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, PARK, true>(A, S, epoch)) return;
+    if (!tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, PARK, WIDE, true>(A, S, epoch)) return;
     __syncthreads();
   }
-  tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, PARK, false>(A, S, epoch);
+  tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, PARK, WIDE, false>(A, S, epoch);
 }
 
 }  // namespace slimamd

@@ -750,13 +750,19 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int tileNW = (nwork + tileP - 1) / tileP >= 2 * m->num_cus ? 8 : 16;
     // (four 4-wavefront workgroups per CU were measured too: no gain, even on columns of ~900 nnz)
     if (const char* e = std::getenv("SLIM_GPU_TILE_NW")) tileNW = std::atoi(e) == 16 ? 16 : 8;
+    // WIDE: where one workgroup per CU is wanted, 8 wavefronts with two blocks each and 256
+    // VGPRs (the previous chunk of a visit stays in registers) instead of 16 with one block
+    bool tile_wide = false;
+    if (const char* e = std::getenv("SLIM_GPU_TILE_WIDE")) tile_wide = std::atoi(e) != 0;
+    tile_wide = tile_wide && use_tile && tileP == 32 && tileNW == 16 && opt.nnbrs == 0;
+    if (tile_wide) tileNW = 8;
     // LDS parking of a visit's second-to-last chunk (a separate instantiation: it costs the
     // visit loop 10-19 % and saves one chunk's re-gather per UPDATING visit).  It pays where
     // nearly every visit of a tile updates some coefficient and slices span several chunks:
     // C5 (+7 %), not C4 (-10 %).  The update share of the previous solve of this matrix decides;
     // before the first solve, the expected density of W (a few thousand entries per column).
     bool lds_park = false;
-    if (use_tile && tileP == 32 && opt.nnbrs == 0 && trace_level < 2) {
+    if (use_tile && tileP == 32 && opt.nnbrs == 0 && trace_level < 2 && !tile_wide) {
       const double dens = m->last_update_share >= 0 ? m->last_update_share
                                                     : std::min(1.0, 3000.0 / std::max(ncols, 1));
       const double tile_upd = 1.0 - std::pow(1.0 - dens, 32.0);
@@ -769,6 +775,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       const bool val = !m->binary;
       if (tileP == 32 && opt.nnbrs > 0)
         fn = tileNW == 16 ? tile_kernel_p32_nw16_extra(val, true) : tile_kernel_p32_nw8_extra(val, true);
+      else if (tile_wide)
+        fn = tile_kernel_p32_wide(val, prof);
       else if (tileP == 32 && lds_park)
         fn = tileNW == 16 ? tile_kernel_p32_nw16_extra(val, false) : tile_kernel_p32_nw8_extra(val, false);
       else if (tileP == 32)
@@ -794,7 +802,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     // co-resident tile workgroups: what the occupancy calculator grants this instantiation
     // (1 x 16 or 2 x 8 wavefronts per CU by design; fewer if the register or LDS footprint
     // of a build ever grows), never more than the design assumes
-    int wg_slots = m->num_cus * (16 / tileNW);
+    int wg_slots = m->num_cus * (tile_wide ? 1 : 16 / tileNW);
     if (use_tile) {
       int per_cu = 0;
       const size_t worst_lds = std::max<size_t>(
@@ -808,7 +816,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         set_error("SLIMGPU_Learn: the tile kernel does not fit a compute unit of this device");
         return fail(SLIM_ERROR);
       }
-      wg_slots = m->num_cus * std::min(per_cu, 16 / tileNW);
+      wg_slots = m->num_cus * std::min(per_cu, tile_wide ? 1 : 16 / tileNW);
     }
     // force_k1: no clusters, no heavy phase -- the geometry that needs no co-residency at all
     // (fallback after a cluster timed out waiting for a member, e.g. under a CU mask)

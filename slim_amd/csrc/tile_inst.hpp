@@ -16,6 +16,8 @@ KernelFn tile_kernel_p16_nw8(bool has_val, bool profile);
 // P = 32 only: neighbour selection (FSLIM) / LDS parking of the second-to-last chunk
 KernelFn tile_kernel_p32_nw16_extra(bool has_val, bool fslim);
 KernelFn tile_kernel_p32_nw8_extra(bool has_val, bool fslim);
+// P = 32, 8 wavefronts, one workgroup per CU, two blocks per wavefront (WIDE)
+KernelFn tile_kernel_p32_wide(bool has_val, bool profile);
 
 #define SLIM_TILE_INSTANTIATE(NAME, PP, NWW)                                        \
   KernelFn NAME(bool has_val, bool profile) {                                        \
@@ -31,6 +33,14 @@ KernelFn tile_kernel_p32_nw8_extra(bool has_val, bool fslim);
                             : cd_tile_kernel<32, true, false, NWW, false, true>)           \
                    : (fslim ? cd_tile_kernel<32, false, false, NWW, true, false>           \
                             : cd_tile_kernel<32, false, false, NWW, false, true>);         \
+  }
+
+#define SLIM_TILE_INSTANTIATE_WIDE(NAME)                                                      \
+  KernelFn NAME(bool has_val, bool profile) {                                                 \
+    return has_val ? (profile ? cd_tile_kernel<32, true, true, 8, false, false, true>         \
+                              : cd_tile_kernel<32, true, false, 8, false, false, true>)       \
+                   : (profile ? cd_tile_kernel<32, false, true, 8, false, false, true>        \
+                              : cd_tile_kernel<32, false, false, 8, false, false, true>);     \
   }
 
 }  // namespace slimamd
