@@ -36,7 +36,6 @@ struct slimgpu_matrix {
   bool binary = false;
   bool owns_csr = false;
   bool exact_gram = false;  // ratings are not small integers: aTy sums formed in a fixed order
-  double last_update_share = -1;  // U / D of the previous solve (-1: none yet)
   // CSR
   int64_t* d_rowptr = nullptr;
   int32_t* d_rowind = nullptr;
@@ -756,20 +755,14 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     if (const char* e = std::getenv("SLIM_GPU_TILE_WIDE")) tile_wide = std::atoi(e) != 0;
     tile_wide = tile_wide && use_tile && tileP == 32 && tileNW == 16 && opt.nnbrs == 0;
     if (tile_wide) tileNW = 8;
-    // LDS parking of a visit's second-to-last chunk (a separate instantiation: it costs the
-    // visit loop 10-19 % and saves one chunk's re-gather per UPDATING visit).  It pays where
-    // nearly every visit of a tile updates some coefficient and slices span several chunks:
-    // C5 (+7 %), not C4 (-10 %).  The update share of the previous solve of this matrix decides;
-    // before the first solve, the expected density of W (a few thousand entries per column).
+    // LDS parking of a visit's second-to-last chunk (a separate instantiation): saves one
+    // chunk's re-gather per updating visit, but the visit loop sits at the 128-VGPR cap and the
+    // extra code costs more than it saves -- C4 -10 %, C5 (where nearly every visit updates and
+    // slices span six chunks) -21 % same-box (profiles/r02/ab_variants.txt).  Off unless
+    // SLIM_GPU_LDS_PARK=1; kept for matrices where it may pay and as a record of the experiment.
     bool lds_park = false;
-    if (use_tile && tileP == 32 && opt.nnbrs == 0 && trace_level < 2 && !tile_wide) {
-      const double dens = m->last_update_share >= 0 ? m->last_update_share
-                                                    : std::min(1.0, 3000.0 / std::max(ncols, 1));
-      const double tile_upd = 1.0 - std::pow(1.0 - dens, 32.0);
-      const double slice = (double)m->nnz / std::max(ncols, 1) / 8.0;  // at a typical K
-      lds_park = tile_upd > 0.9 && slice >= 2.0 * 64 * tileNW;
+    if (use_tile && tileP == 32 && opt.nnbrs == 0 && trace_level < 2 && !tile_wide)
       if (const char* e = std::getenv("SLIM_GPU_LDS_PARK")) lds_park = std::atoi(e) != 0;
-    }
     if (use_tile) {
       const bool prof = trace_level >= 2;
       const bool val = !m->binary;
@@ -1289,7 +1282,6 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       st.objval += h_obj[c];
     }
     st.nnzW = tnnz;
-    if (st.D > 0) m->last_update_share = (double)st.U / (double)st.D;
     st.alg_bytes = m->binary
                        ? 4.0 * st.G + 8.0 * st.D + 4.0 * st.U + 8.0 * st.nnzW
                        : 8.0 * st.G + 12.0 * st.D + 4.0 * st.U + 8.0 * st.nnzW;
