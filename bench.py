@@ -372,7 +372,7 @@ def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts,
 
     # one column on one thread sizes everything else
     _, t1 = timed(pool[:1], 1, gram)
-    n1 = int(max(1, min(4, args.cpu_seconds // max(t1, 1e-3))))
+    n1 = int(max(1, min(2, args.cpu_seconds // max(t1, 1e-3))))
     res = {}
     _, t = timed(pool[:n1], 1, gram)
     res["gram_localprng_1thread"] = {"value": n1 / t, "columns": n1, "seconds": round(t, 2), "threads": 1}
@@ -382,7 +382,7 @@ def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts,
     # alone (the cores share the memory system), so the round count comes from a first round
     use = max(1, min(cores, span))
     Wc, t = timed(pool[:use], use, gram)
-    rounds = int(max(1, min(span // use, 2, args.cpu_seconds // max(t, 1e-3))))
+    rounds = int(max(1, min(span // use, 2, (args.cpu_seconds / 2) // max(t, 1e-3))))
     sample = pool[:use * rounds]
     if rounds > 1:
         Wc, t = timed(sample, use, gram)

@@ -67,6 +67,9 @@ constexpr int kTileNW = 16;  // wavefronts per workgroup (default geometry)
 #define SLIM_TILE_ID_PIPE 0   // request the ids of chunk c+1 before gathering chunk c
                               // (measured: 61.3 vs 60.0 s per C4 step, same box -- off)
 #endif
+#ifndef SLIM_TILE_SCREEN_GS
+#define SLIM_TILE_SCREEN_GS 8  // screen pass: gather steps in flight per lane
+#endif
 #ifndef SLIM_TILE_PF_ALL
 #define SLIM_TILE_PF_ALL 0    // next visit's first ids requested during the exchange in every
 #endif                        // phase (1) or in the heavy phase only (0)
@@ -271,7 +274,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     //    float atomic per touched (item, problem): 1.2 s of a 12.9 s median tile on C4, 7 s of
     //    the 27 s heaviest tile.)
     {
-      constexpr int GS = 8;  // gather steps in flight per lane
+      constexpr int GS = SLIM_TILE_SCREEN_GS;  // gather steps in flight per lane
       for (int i = wave; i < ncols; i += NW) {
         const int64_t cs = uni(csplit[(int64_t)i * (K + 1) + mk]);
         const int64_t ce = uni(csplit[(int64_t)i * (K + 1) + mk + 1]);
@@ -854,11 +857,13 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         prof[6] += upd ? 1 : 0;
       }
     };
-    auto visit = [&](auto... args) {
+    auto visit = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
+                     const float xi, const float cn, const float sq, const bool live, float& dlt,
+                     const int mode, const int64_t sn_v, const int nn_v) {
       if constexpr (WIDE)
-        visit_wide(args...);
+        visit_wide(i, s, e, len, xi, cn, sq, live, dlt, mode, sn_v, nn_v);
       else
-        visit_std(args...);
+        visit_std(i, s, e, len, xi, cn, sq, live, dlt, mode, sn_v, nn_v);
     };
 
     const uint64_t t_setup = wall_clock64();

@@ -839,7 +839,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         // per-visit exchange.  Cost is only a proxy for time, so the test is generous (a
         // light tile solved by a big cluster wastes a few CU-seconds, a heavy one solved by
         // a small cluster is the critical path of the launch).
-        if (opt.heavy_tiles < 0 && tileNW == 16 && ngroups_all >= 16) {
+        if (opt.heavy_tiles < 0 && (tileNW == 16 || tile_wide) && ngroups_all >= 16) {
           auto tile_cost = [&](int gI) {
             int64_t c = 0;
             for (int t = gI * tileP; t < std::min((gI + 1) * tileP, nwork); ++t)
