@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void topn_kernel(const TopNArgs T) {
 //     merged through LDS by wavefront 0.
 constexpr int kT2Waves = 8;       // default workgroup: 8 wavefronts x 1536-id chunks
 constexpr int kT2Depth = 16;
-constexpr int kT2MaxN = 32;
+constexpr int kT2MaxN = 64;       // lists live one rank per lane: up to a wavefront's width
 constexpr int kT2MaxCW = 1536;
 
 struct TopN2Args {
@@ -538,7 +538,7 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
     TOPN_TRY(hipMemset(d_queue.p, 0, 2 * sizeof(int32_t)));
     TOPN_TRY(hipMemset(d_ocnt.p, 0, sizeof(int32_t) * (size_t)nusers));
 
-    // kernel choice: score chunks in LDS (lists of up to 32, rows of W sorted by id), else the
+    // kernel choice: score chunks in LDS (lists of up to 64, rows of W sorted by id), else the
     // one-wavefront-per-user kernel with its vectors in HBM.  SLIM_TOPN_KERNEL=wave|chunk and
     // SLIM_TOPN_CW=<chunk width> override (tests).
     const char* kenv = std::getenv("SLIM_TOPN_KERNEL");
@@ -575,7 +575,7 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
     if (chunked && (size_t)W->nrows * ((size_t)nchunks + 1) * sizeof(uint32_t) > (size_t(2) << 30))
       chunked = false;
     if (kenv && std::strcmp(kenv, "chunk") == 0 && !chunked) {
-      set_error("SLIMGPU_Predict: SLIM_TOPN_KERNEL=chunk needs nrcmds <= 32 and model rows sorted by id");
+      set_error("SLIMGPU_Predict: SLIM_TOPN_KERNEL=chunk needs nrcmds <= 64 and model rows sorted by id");
       return SLIM_ERROR_INPUT;
     }
 

@@ -566,7 +566,7 @@ def test_gpu_topn_chunk_kernel_wide_model():
     for env in ({"SLIM_TOPN_KERNEL": "chunk"}, {"SLIM_TOPN_KERNEL": "chunk", "SLIM_TOPN_CW": "640"},
                 {"SLIM_TOPN_KERNEL": "chunk", "SLIM_TOPN_KEY": "64", "SLIM_TOPN_WAVES": "16"},
                 {"SLIM_TOPN_KERNEL": "wave"}):
-        for N in (10, 32):
+        for N in (10, 32, 64):
             ids_o, sc_o = O.predict(W, H, N)
             ids_g, sc_g, ids_c, sc_c = _predict_both(lib, hW, hH, nu, N, env)
             assert np.array_equal(ids_g, ids_o) and np.array_equal(sc_g, sc_o), (env, N)
