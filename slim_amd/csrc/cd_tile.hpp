@@ -62,17 +62,6 @@
 namespace slimamd {
 
 constexpr int kTileNW = 16;  // wavefronts per workgroup (default geometry)
-// experiments (A/B through -D at build time; the defaults are what measured best)
-#ifndef SLIM_TILE_ID_PIPE
-#define SLIM_TILE_ID_PIPE 0   // request the ids of chunk c+1 before gathering chunk c
-                              // (measured: 61.3 vs 60.0 s per C4 step, same box -- off)
-#endif
-#ifndef SLIM_TILE_SCREEN_GS
-#define SLIM_TILE_SCREEN_GS 8  // screen pass: gather steps in flight per lane
-#endif
-#ifndef SLIM_TILE_PF_ALL
-#define SLIM_TILE_PF_ALL 0    // next visit's first ids requested during the exchange in every
-#endif                        // phase (1) or in the heavy phase only (0)
 constexpr int kTileKMax = 32;  // largest cluster (workgroups sharing one tile)
 constexpr float kInactive = -__builtin_huge_valf();
 __device__ __forceinline__ bool tile_active(float xv) { return xv > -3.0e38f; }
@@ -95,7 +84,7 @@ __device__ __forceinline__ tile_gran_t gran_load(const tile_gran_t* p) {
 // phase is a template parameter so that the cluster geometry stays a function of kernel
 // arguments (re-derivable, no live registers across the visit loop).  Returns false when
 // the launch was aborted.
-template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM, bool PARK, bool WIDE, bool HI>
+template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM, bool HI>
 __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& S, uint32_t& epoch) {
   constexpr int NT = 64 * NW;  // threads per workgroup
   constexpr int SL = 64 / P;       // users per wavefront step (lane groups)
@@ -274,7 +263,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     //    float atomic per touched (item, problem): 1.2 s of a 12.9 s median tile on C4, 7 s of
     //    the 27 s heaviest tile.)
     {
-      constexpr int GS = SLIM_TILE_SCREEN_GS;  // gather steps in flight per lane
+      constexpr int GS = 8;  // gather steps in flight per lane (16: no gain, measured)
       for (int i = wave; i < ncols; i += NW) {
         const int64_t cs = uni(csplit[(int64_t)i * (K + 1) + mk]);
         const int64_t ce = uni(csplit[(int64_t)i * (K + 1) + mk + 1]);
@@ -507,7 +496,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     int pf_id = 0;
     float pf_v = 0.0f;
     int64_t pf_at = -1;  // slice start the prefetched block belongs to (-1: none)
-    auto visit_std = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
+    auto visit = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
                      const float xi, const float cn, const float sq, const bool live, float& dlt,
                      const int mode, const int64_t sn_v, const int nn_v) {
       int64_t pf_here = pf_at;  // valid for the first load of the first block only
@@ -525,7 +514,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         const int64_t left = e - b0;
         nhere = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
         const bool ok = lane < nhere;
-        if ((HI || SLIM_TILE_PF_ALL) && c0 == pf_here) {  // requested during the previous visit
+        if (HI && c0 == pf_here) {  // requested during the previous visit
           idreg = pf_id;
           vreg = pf_v;
           pf_here = -1;  // (pf_id is reused for the next visit before this block is re-read)
@@ -572,67 +561,23 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         }
       };
 
-      // The chunk before the last one is parked in LDS (ids, values and the P gathered
-      // residuals of this wavefront's 64 nnz: 8.5 KB per wavefront), the last one stays in
-      // registers: slices of up to two chunks are updated without touching HBM for reads, and
-      // longer ones re-gather one chunk less.
-      float* const park = reinterpret_cast<float*>(s_bits) + wave * (64 * (STEPS + 2));
-      auto park_put = [&]() {
-        if (nhere > 0) {
-#pragma unroll
-          for (int j = 0; j < STEPS; ++j) park[j * 64 + lane] = r_c[j];
-        }
-        park[STEPS * 64 + lane] = __int_as_float(idreg);
-        park[(STEPS + 1) * 64 + lane] = vreg;
-      };
-      auto park_get = [&](const int64_t c) {
-        const int64_t left = e - (c + 64 * wave);
-        nhere = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
-        idreg = __float_as_int(park[STEPS * 64 + lane]);
-        vreg = park[(STEPS + 1) * 64 + lane];
-        if (nhere > 0) {
-#pragma unroll
-          for (int j = 0; j < STEPS; ++j) r_c[j] = park[j * 64 + lane];
-        }
-      };
       const uint64_t p0 = tick();
       float acc = 0.0f;
       int64_t c0 = s;
-#if SLIM_TILE_ID_PIPE
-      // the ids (and values) of chunk c+1 are requested before chunk c is gathered, so a chunk's
-      // gathers never wait for an id load issued after the previous chunk's dot
-      load_ids(c0);
-      for (; c0 + CH < e; c0 += CH) {
-        const int64_t b1 = c0 + CH + 64 * wave;
-        const int64_t left1 = e - b1;
-        const int n1 = left1 <= 0 ? 0 : (left1 < 64 ? (int)left1 : 64);
-        const int id_nx = lane < n1 ? ci[b1 + lane] - ubase : 0;
-        const float v_nx = lane < n1 ? (HAS_VAL ? cv[b1 + lane] : 1.0f) : 0.0f;
-        gather();
-        if (mode == 0) acc += dot_block();
-        if (PARK && c0 + 2 * CH >= e) park_put();
-        idreg = id_nx;
-        vreg = v_nx;
-        nhere = n1;
-      }
-      gather();  // last chunk: kept in registers for the update
-#else
       for (; c0 + CH < e; c0 += CH) {
         load_ids(c0);
         gather();
         if (mode == 0) acc += dot_block();
-        if (PARK && c0 + 2 * CH >= e) park_put();
       }
       load_ids(c0);  // last chunk: kept in registers for the update
       gather();
-#endif
       // (sn_v / nn_v are still in flight when the visit starts: made uniform only here.)  The
       // loads are unconditional instructions with a clamped address -- lanes past the slice hold
       // garbage that load_ids never looks at -- so that exactly one (two with values) load is in
       // flight behind the gather on every path and the dot below waits for the gather only
       // (s_waitcnt vmcnt(1|2)); a load under a condition makes the count path-dependent and the
       // compiler drains the queue instead.
-      if ((HI || SLIM_TILE_PF_ALL) && mode == 0) {
+      if (HI && mode == 0) {
         const int64_t sn = uni(sn_v);
         const int nn = uni(nn_v);
         int64_t jj = sn + 64 * wave + lane;
@@ -678,13 +623,9 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       const uint64_t p3 = tick();
       if (upd) {
         scatter(d);
-        for (int64_t c = s; c < c0; c += CH) {  // earlier chunks: from LDS, or re-gathered
-          if (PARK && c + 2 * CH >= e) {
-            park_get(c);
-          } else {
-            load_ids(c);
-            gather();
-          }
+        for (int64_t c = s; c < c0; c += CH) {  // earlier chunks: re-read (L2 / Infinity Cache)
+          load_ids(c);
+          gather();
           scatter(d);
         }
       }
@@ -701,169 +642,6 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         prof[5] += 1;
         prof[6] += upd ? 1 : 0;
       }
-    };
-
-    // The WIDE form of a visit (see cd_tile_kernel): the same arithmetic, two blocks per
-    // wavefront, the chunk before the current one kept in registers.
-    struct Blk {
-      int id;
-      float v;
-      int n;
-      float r[STEPS];
-    };
-    auto visit_wide = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
-                          const float xi, const float cn, const float sq, const bool live,
-                          float& dlt, const int mode, const int64_t, const int) {
-      const bool part = live && tile_active(xi);
-      if (!__any(part)) return;
-      constexpr int64_t CH = 128 * NW;  // nnz per workgroup chunk
-      auto ids = [&](Blk& b, const int64_t b0) {
-        const int64_t left = e - b0;
-        b.n = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
-        const bool ok = lane < b.n;
-        b.id = ok ? ci[b0 + lane] - ubase : 0;
-        b.v = ok ? (HAS_VAL ? cv[b0 + lane] : 1.0f) : 0.0f;
-      };
-      auto gather = [&](Blk& b) {
-        if (b.n > 0) {
-#pragma unroll
-          for (int j = 0; j < STEPS; ++j) {
-            const int src = j * SL + slot;
-            const int u = __shfl(b.id, src);
-            b.r[j] = 0.0f;
-            if (src < b.n)
-              b.r[j] = *reinterpret_cast<const float*>(rb + (((uint32_t)u * (uint32_t)(4 * P)) | qoff));
-          }
-        }
-      };
-      auto settle = [&](Blk& b) {
-        if (b.n > 0) {
-#pragma unroll
-          for (int j = 0; j < STEPS; ++j) pin(b.r[j]);
-        }
-      };
-      auto dot_blk = [&](const Blk& b) -> float {
-        float a = 0.0f;
-        if (b.n > 0) {
-#pragma unroll
-          for (int j = 0; j < STEPS; ++j) a += __shfl(b.v, j * SL + slot) * b.r[j];
-        }
-        return a;
-      };
-      auto scatter = [&](const Blk& b, const float d) {
-        if (b.n > 0) {
-#pragma unroll
-          for (int j = 0; j < STEPS; ++j) {
-            const int src = j * SL + slot;
-            const int u = __shfl(b.id, src);
-            const float v = __shfl(b.v, src);
-            if (src < b.n)
-              *reinterpret_cast<float*>(rbw + (((uint32_t)u * (uint32_t)(4 * P)) | qoff)) =
-                  b.r[j] - d * v;
-          }
-        }
-      };
-      const uint64_t p0 = tick();
-      Blk a0, a1, k0, k1;  // current chunk, previous chunk
-      k0.n = k1.n = 0;
-      k0.id = k1.id = 0;
-      k0.v = k1.v = 0.0f;
-      bool kept = false;
-      float acc = 0.0f;
-      int64_t c0 = s;
-      ids(a0, c0 + 128 * wave);
-      ids(a1, c0 + 128 * wave + 64);
-      for (; c0 + CH < e; c0 += CH) {
-        Blk n0, n1;  // (only id / v / n are used: the next chunk's ids go out first)
-        ids(n0, c0 + CH + 128 * wave);
-        ids(n1, c0 + CH + 128 * wave + 64);
-        gather(a0);
-        gather(a1);
-        settle(a0);
-        settle(a1);
-        if (mode == 0) acc += dot_blk(a0) + dot_blk(a1);
-        k0 = a0;
-        k1 = a1;
-        kept = true;
-        a0.id = n0.id; a0.v = n0.v; a0.n = n0.n;
-        a1.id = n1.id; a1.v = n1.v; a1.n = n1.n;
-      }
-      gather(a0);
-      gather(a1);
-      settle(a0);
-      settle(a1);
-      const uint64_t p1 = tick();
-
-      float d = 0.0f, nx = xi;
-      uint64_t p2 = p1;
-      if (mode == 0) {
-        acc += dot_blk(a0) + dot_blk(a1);
-        if (SL == 4) acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
-        if (slot == 0) s_part[buf][wave][q] = acc;
-        __syncthreads();
-        float dot = 0.0f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) dot += s_part[buf][w][q];
-        buf ^= 1;
-        dot = cluster_sum(dot);
-        p2 = tick();
-        const float xeff = (xi > kEps || xi < -kEps) ? xi : 0.0f;
-        const float num = dot + xeff * sq;
-        nx = num > l1 ? (num - l1) / (cn * cn + l2) : 0.0f;
-        const float neff = (nx > kEps || nx < -kEps) ? nx : 0.0f;
-        d = neff - xeff;
-        if (!part) {
-          d = 0.0f;
-          nx = xi;
-        } else {
-          D_q += len;
-          dlt += (nx - xi) * (nx - xi);
-          if (d != 0.0f) U_q += len;
-        }
-      } else {
-        d = (part && (xi > kEps || xi < -kEps)) ? xi : 0.0f;
-      }
-      const bool upd = __any(d != 0.0f);
-      const bool xch = mode == 0 && __any(part && nx != xi);
-      const uint64_t p3 = tick();
-      if (upd) {
-        scatter(a0, d);
-        scatter(a1, d);
-        if (kept) {
-          scatter(k0, d);
-          scatter(k1, d);
-        }
-        for (int64_t c = s; c + CH < c0; c += CH) {  // chunks before the kept one: re-gathered
-          ids(a0, c + 128 * wave);
-          ids(a1, c + 128 * wave + 64);
-          gather(a0);
-          gather(a1);
-          scatter(a0, d);
-          scatter(a1, d);
-        }
-      }
-      if (xch && wave == 0 && slot == 0 && part && nx != xi) x[(int64_t)i * P + q] = nx;
-      const uint64_t p4 = PROFILE ? clock64() : 0;
-      if (upd || xch) __syncthreads();
-      if (PROFILE) {
-        const uint64_t p5 = clock64();
-        prof[0] += p1 - p0;
-        prof[1] += p2 - p1;
-        prof[2] += p3 - p2;
-        prof[3] += p4 - p3;
-        prof[4] += p5 - p4;
-        prof[5] += 1;
-        prof[6] += upd ? 1 : 0;
-      }
-    };
-    auto visit = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
-                     const float xi, const float cn, const float sq, const bool live, float& dlt,
-                     const int mode, const int64_t sn_v, const int nn_v) {
-      if constexpr (WIDE)
-        visit_wide(i, s, e, len, xi, cn, sq, live, dlt, mode, sn_v, nn_v);
-      else
-        visit_std(i, s, e, len, xi, cn, sq, live, dlt, mode, sn_v, nn_v);
     };
 
     const uint64_t t_setup = wall_clock64();
@@ -1028,26 +806,21 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 // -- gather / barrier / cluster exchange / write-back -- then overlap).
 // (16 wavefronts per CU either way: the second launch bound, 4 waves per SIMD, caps the
 // kernel at 128 VGPRs)
-// FSLIM (neighbour selection instead of the l1 screen) and PARK (second-to-last chunk of a visit
-// kept in LDS) are separate instantiations: the visit loop sits at the 128-VGPR cap, and code
-// that merely exists in the same kernel costs it 5 % (the FSLIM block) to 10-19 % (parking) --
-// measured same-box on C4 (profiles/r02/ab_variants.txt); parking pays only where nearly every
-// visit updates and slices are long (C5: +7 % net).
-// WIDE: 8 wavefronts, ONE workgroup per CU, two 64-nnz blocks per wavefront and chunk -- 2 waves
-// per SIMD leave 256 VGPRs each (no spills), enough to hold the previous chunk of a visit in
-// registers next to the current one: slices of up to two 1024-nnz chunks update without
-// re-gathering, with the same number of line requests in flight per CU as 16 x 1 block.
-template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM = false, bool PARK = false,
-          bool WIDE = false>
-__global__ __launch_bounds__(64 * NW, WIDE ? 2 : 4) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
+// FSLIM (neighbour selection instead of the l1 screen) is a separate instantiation: the visit
+// loop sits at the 128-VGPR cap, and code that merely exists in the same kernel costs it 5 %
+// (measured same-box on C4, profiles/r02/ab_variants.txt; the same runs rejected parking a
+// chunk of a visit in LDS, pipelining the id loads of a visit's chunks, and an 8-wavefront /
+// 256-VGPR form of the workgroup).
+template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM = false>
+__global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
   uint32_t epoch = 0;
   // heavy phase first: whole clusters of S.cluster_hi only (S.cluster divides S.cluster_hi,
   // so the workgroups of a big cluster regroup into whole small ones afterwards)
   if (S.nheavy > 0 && (int)blockIdx.x < ((int)gridDim.x / S.cluster_hi) * S.cluster_hi) {
-    if (!tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, PARK, WIDE, true>(A, S, epoch)) return;
+    if (!tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, true>(A, S, epoch)) return;
     __syncthreads();
   }
-  tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, PARK, WIDE, false>(A, S, epoch);
+  tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, false>(A, S, epoch);
 }
 
 }  // namespace slimamd

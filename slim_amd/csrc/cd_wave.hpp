@@ -84,7 +84,6 @@ struct SolveArgs {
                                  // the screen pass over the member's users
   int32_t exact_gram;            // 1: no float atomics in the aTy sums (ratings are not small
                                  // integers, where any order gives the same float)
-  int32_t lds_park;              // tile kernels: keep the second-to-last chunk of a visit in LDS
   int32_t bm_shift, bm_words;    // LDS user bitmap: one bit per 1 << bm_shift users, bm_words words
   // heavy-tile phase: the first nheavy tiles of the work list (the most expensive ones) are
   // solved by clusters of cluster_hi workgroups before the launch regroups into clusters

@@ -749,29 +749,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int tileNW = (nwork + tileP - 1) / tileP >= 2 * m->num_cus ? 8 : 16;
     // (four 4-wavefront workgroups per CU were measured too: no gain, even on columns of ~900 nnz)
     if (const char* e = std::getenv("SLIM_GPU_TILE_NW")) tileNW = std::atoi(e) == 16 ? 16 : 8;
-    // WIDE: where one workgroup per CU is wanted, 8 wavefronts with two blocks each and 256
-    // VGPRs (the previous chunk of a visit stays in registers) instead of 16 with one block
-    bool tile_wide = false;
-    if (const char* e = std::getenv("SLIM_GPU_TILE_WIDE")) tile_wide = std::atoi(e) != 0;
-    tile_wide = tile_wide && use_tile && tileP == 32 && tileNW == 16 && opt.nnbrs == 0;
-    if (tile_wide) tileNW = 8;
-    // LDS parking of a visit's second-to-last chunk (a separate instantiation): saves one
-    // chunk's re-gather per updating visit, but the visit loop sits at the 128-VGPR cap and the
-    // extra code costs more than it saves -- C4 -10 %, C5 (where nearly every visit updates and
-    // slices span six chunks) -21 % same-box (profiles/r02/ab_variants.txt).  Off unless
-    // SLIM_GPU_LDS_PARK=1; kept for matrices where it may pay and as a record of the experiment.
-    bool lds_park = false;
-    if (use_tile && tileP == 32 && opt.nnbrs == 0 && trace_level < 2 && !tile_wide)
-      if (const char* e = std::getenv("SLIM_GPU_LDS_PARK")) lds_park = std::atoi(e) != 0;
     if (use_tile) {
       const bool prof = trace_level >= 2;
       const bool val = !m->binary;
       if (tileP == 32 && opt.nnbrs > 0)
-        fn = tileNW == 16 ? tile_kernel_p32_nw16_extra(val, true) : tile_kernel_p32_nw8_extra(val, true);
-      else if (tile_wide)
-        fn = tile_kernel_p32_wide(val, prof);
-      else if (tileP == 32 && lds_park)
-        fn = tileNW == 16 ? tile_kernel_p32_nw16_extra(val, false) : tile_kernel_p32_nw8_extra(val, false);
+        fn = tile_kernel_p32_fslim(val, tileNW == 16);
       else if (tileP == 32)
         fn = tileNW == 16 ? tile_kernel_p32_nw16(val, prof) : tile_kernel_p32_nw8(val, prof);
       else
@@ -795,21 +777,17 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     // co-resident tile workgroups: what the occupancy calculator grants this instantiation
     // (1 x 16 or 2 x 8 wavefronts per CU by design; fewer if the register or LDS footprint
     // of a build ever grows), never more than the design assumes
-    int wg_slots = m->num_cus * (tile_wide ? 1 : 16 / tileNW);
+    int wg_slots = m->num_cus * (16 / tileNW);
     if (use_tile) {
       int per_cu = 0;
-      const size_t worst_lds = std::max<size_t>(
-          kBitmapBytes, lds_park ? (size_t)tileNW * 64 * ((size_t)tileP + 2) * sizeof(float) : (size_t)0);
-      if (worst_lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)worst_lds));
+      const size_t worst_lds = kBitmapBytes;
       HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn),
                                                            64 * tileNW, worst_lds));
       if (per_cu < 1) {
         set_error("SLIMGPU_Learn: the tile kernel does not fit a compute unit of this device");
         return fail(SLIM_ERROR);
       }
-      wg_slots = m->num_cus * std::min(per_cu, tile_wide ? 1 : 16 / tileNW);
+      wg_slots = m->num_cus * std::min(per_cu, 16 / tileNW);
     }
     // force_k1: no clusters, no heavy phase -- the geometry that needs no co-residency at all
     // (fallback after a cluster timed out waiting for a member, e.g. under a CU mask)
@@ -839,7 +817,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         // per-visit exchange.  Cost is only a proxy for time, so the test is generous (a
         // light tile solved by a big cluster wastes a few CU-seconds, a heavy one solved by
         // a small cluster is the critical path of the launch).
-        if (opt.heavy_tiles < 0 && (tileNW == 16 || tile_wide) && ngroups_all >= 16) {
+        if (opt.heavy_tiles < 0 && tileNW == 16 && ngroups_all >= 16) {
           auto tile_cost = [&](int gI) {
             int64_t c = 0;
             for (int t = gI * tileP; t < std::min((gI + 1) * tileP, nwork); ++t)
@@ -927,16 +905,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       if (opt.nnbrs > 0) bm_words = std::max(bm_words, tileP * 256);  // FSLIM's select histograms
     };
     // dynamic LDS of a tile workgroup: the user bitmap of the screen pass (FSLIM: the select
-    // histograms), reused during the sweeps as the parking area of one chunk per wavefront
-    // (64 nnz x (P residuals + id + value) = 8.5 KB at P = 32)
+    // histograms)
     size_t tile_lds = 0;
     if (use_tile) {
       alloc_tiles();
-      const size_t park_bytes = (size_t)tileNW * 64 * ((size_t)tileP + 2) * sizeof(float);
-      tile_lds = std::max(sizeof(uint32_t) * (size_t)bm_words, lds_park ? park_bytes : (size_t)0);
-      if (tile_lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+      tile_lds = sizeof(uint32_t) * (size_t)bm_words;
     } else if (!use_lds) {
       d_slab = ws_get<float>(m->ws_slab, vec_floats * (size_t)nwaves);
     }
@@ -1052,7 +1025,6 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.csplit = use_tile ? m->d_csplit[cluster_lg] : nullptr;
       S.mailbox = d_mailbox;
       S.exact_gram = (m->exact_gram || std::getenv("SLIM_GPU_EXACT_GRAM")) ? 1 : 0;
-      S.lds_park = lds_park ? 1 : 0;
       S.atypart = d_part;
       S.bm_shift = bm_shift;
       S.bm_words = bm_words;

@@ -853,31 +853,3 @@ def test_gpu_1vsk_matches_oracle(ml100k, ml_gpu):
             assert np.array_equal(sc.reshape(nu, n), sc_o), (nnegs, n, env)
     lib.Py_csr_free(hr)
     lib.SLIM_FreeModel(C.byref(hm))
-
-
-@pytest.mark.parametrize("geom", [{"cluster": 1}, {"cluster": 4},
-                                  {"cluster": 2, "heavy_tiles": 4, "heavy_cluster": 8}])
-def test_tile_kernel_wide_instantiation(ml100k, monkeypatch, geom):
-    """The WIDE form of the tile kernel (8 wavefronts, two 64-nnz blocks each, the previous chunk
-    of a visit kept in registers): the same walk of the same tiles as the oracle, also on a matrix
-    whose slices span several chunks (users x 40 so that columns hold thousands of nnz)."""
-    monkeypatch.setenv("SLIM_GPU_TILE_WIDE", "1")
-    R, _ = ml100k
-    big = sp.vstack([R] * 40).tocsr()            # 37 360 users: popular columns ~ 20K nnz
-    for M in (R, big):
-        m = DeviceMatrix.from_scipy(M)
-        cols = np.arange(0, 256, dtype=np.int32) if M is big else None
-        W, st = m.learn(seed=1, kernel=KERNEL_TILE, columns=cols, **geom)
-        cs = m.column_stats()
-        assert st["kernel"] == KERNEL_TILE
-        if cols is None:
-            order = O.tile_work_order(M)
-        else:
-            cost = m.column_cost()
-            order = cols[np.argsort(-cost[cols], kind="stable")]
-        Wo, so, _, _ = O.learn_cd_tile(M, tileP=32, order=order, seed=1, nthreads=8, return_stats=True)
-        sel = order
-        assert maxdiff(W[:, sel], Wo[:, sel]) <= 2e-5
-        assert (cs.sweeps[sel] == so["sweeps"][sel]).mean() >= 0.99
-        assert np.array_equal(cs.nacols[sel], so["nacols"][sel])
-        m.close()
