@@ -375,9 +375,9 @@ def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts,
     n1 = int(max(1, min(2, args.cpu_seconds // max(t1, 1e-3))))
     res = {}
     _, t = timed(pool[:n1], 1, gram)
-    res["gram_localprng_1thread"] = {"value": n1 / t, "columns": n1, "seconds": round(t, 2), "threads": 1}
+    res["gram_localprng_1thread"] = {"value": n1 / t, "columns": n1, "seconds": round(t, 3), "threads": 1}
     _, t = timed(pool[:n1], 1, faithful)
-    res["fullscan_rand_1thread"] = {"value": n1 / t, "columns": n1, "seconds": round(t, 2), "threads": 1}
+    res["fullscan_rand_1thread"] = {"value": n1 / t, "columns": n1, "seconds": round(t, 3), "threads": 1}
     # all physical cores, one column per core and round; a round takes longer than one column
     # alone (the cores share the memory system), so the round count comes from a first round
     use = max(1, min(cores, span))
@@ -387,9 +387,9 @@ def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts,
     if rounds > 1:
         Wc, t = timed(sample, use, gram)
     res["gram_localprng_allcores"] = {"value": sample.size / t, "columns": int(sample.size),
-                                      "seconds": round(t, 2), "threads": use}
+                                      "seconds": round(t, 3), "threads": use}
     _, tf = timed(pool[:use], use, faithful)
-    res["fullscan_rand_allcores"] = {"value": use / tf, "columns": use, "seconds": round(tf, 2),
+    res["fullscan_rand_allcores"] = {"value": use / tf, "columns": use, "seconds": round(tf, 3),
                                      "threads": use}
     # parity of the GPU's columns
     sample = np.sort(sample)
