@@ -51,7 +51,7 @@ def parse_args():
                     help="weak: --batch columns per GPU and step; strong: --batch columns per "
                          "step in total, split over the GPUs (--batch 0 = the whole matrix)")
     ap.add_argument("--warmup-batch", type=int, default=0,
-                    help="columns per GPU of an (untimed) warm-up step (0 = batch / 8)")
+                    help="columns per GPU of an (untimed) warm-up step (0 = batch / 32)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ratings", action="store_true", help="ratings 1..5 instead of binary values")
     ap.add_argument("--kernel", type=int, default=0, help="slimgpu_kernel_et (0 = auto)")
@@ -59,6 +59,9 @@ def parse_args():
                     help="tile kernels: workgroups per tile, 1/2/4/8 (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="CPU-baseline budget per measured mode (0 disables the leg)")
+    ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("SLIM_BENCH_CPU_THREADS", "32")),
+                    help="threads of the parallel CPU-baseline modes (0 = all physical cores; on "
+                         "the 128-core boxes of this pool one round then takes ~3 minutes)")
     ap.add_argument("--replicate", default="broadcast", choices=["broadcast", "generate"])
     ap.add_argument("--backend", default=os.environ.get("SLIM_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several "
@@ -153,7 +156,7 @@ def main():
         span = min(ncols, args.batch or ncols)
     else:
         span = min(ncols, per_gpu * world)
-    warm_span = min(span, world * (args.warmup_batch or max(1024, per_gpu // 8)))
+    warm_span = min(span, world * (args.warmup_batch or max(256, per_gpu // 32)))
     opts = dict(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=args.seed, kernel=args.kernel)
     if args.cluster:
         opts["cluster"] = args.cluster
@@ -378,9 +381,12 @@ def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts,
     res["gram_localprng_1thread"] = {"value": n1 / t, "columns": n1, "seconds": round(t, 3), "threads": 1}
     _, t = timed(pool[:n1], 1, faithful)
     res["fullscan_rand_1thread"] = {"value": n1 / t, "columns": n1, "seconds": round(t, 3), "threads": 1}
-    # all physical cores, one column per core and round; a round takes longer than one column
-    # alone (the cores share the memory system), so the round count comes from a first round
-    use = max(1, min(cores, span))
+    # the parallel modes: one column per thread and round, on --cpu-threads threads (default 32:
+    # on the 2 x 64-core hosts of this pool 128 concurrent columns thrash the memory system --
+    # 0.73 col/s on 128 threads against ~2.5 on 32, profiles/r02/cpu_baseline_128threads.txt --
+    # and one such round takes three minutes); a round takes longer than one column alone, so
+    # the round count comes from a first round
+    use = max(1, min(args.cpu_threads or cores, cores, span))
     Wc, t = timed(pool[:use], use, gram)
     rounds = int(max(1, min(span // use, 2, (args.cpu_seconds / 2) // max(t, 1e-3))))
     sample = pool[:use * rounds]
@@ -417,7 +423,7 @@ def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts,
         "sample": "%d of the %d columns of the last GPU step (seeded choice), %.1f s of CPU "
                   "work, estimate phase only; oracle/slim_oracle.c, reference arithmetic (fp64, "
                   "3-pass), thread-local PRNG shuffle + Gram-column aTy, OpenMP one column per "
-                  "physical core" % (best["columns"], span, best["seconds"]),
+                  "thread on %d threads" % (best["columns"], span, best["seconds"], best["threads"]),
         "modes": res,
         "parity": {
             "tile_order_max_abs_dW": d_tile, "tile": "tile %d of %d of the last step" % (g, ntiles),

@@ -8,7 +8,8 @@
 #   3. scripts/pmc_to_json.py -> an entry (keyed by configuration, seed and the hash of the
 #      kernel sources) appended to profiles/pmc_traffic.json, which bench.py looks up
 # usage: bash scripts/collect_profiles.sh TAG [bench.py args...]   (outputs: gpurun_out/TAG_*)
-#   SKIP_STATS=1 skips step 1; STEPS/WARMUP set the stats run (default 1 / 1)
+#   SKIP_STATS=1 skips step 1; STEPS/WARMUP set the stats run (default 2 / 0: the kernel's
+#   average duration in the stats is then the average of the timed launches)
 set -u
 TAG=${1:-r02_c4}
 shift || true
@@ -20,7 +21,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 if [ -z "${SKIP_STATS:-}" ]; then
   export SLIM_GPU_TRACE=1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o run -- python $R/bench.py --steps ${STEPS:-1} --warmup ${WARMUP:-1} $ARGS > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o run -- python $R/bench.py --steps ${STEPS:-2} --warmup ${WARMUP:-0} $ARGS > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
   unset SLIM_GPU_TRACE
 fi
 for c in FETCH_SIZE WRITE_SIZE; do
