@@ -8,7 +8,7 @@
 #   3. scripts/pmc_to_json.py -> an entry (keyed by configuration, seed and the hash of the
 #      kernel sources) appended to profiles/pmc_traffic.json, which bench.py looks up
 # usage: bash scripts/collect_profiles.sh TAG [bench.py args...]   (outputs: gpurun_out/TAG_*)
-#   SKIP_STATS=1 skips step 1; STEPS/WARMUP set the stats run (default 2 / 0: the kernel's
+#   SKIP_STATS=1 skips step 1, SKIP_PMC=1 steps 2-3; STEPS/WARMUP set the stats run (default 2 / 0: the kernel's
 #   average duration in the stats is then the average of the timed launches)
 set -u
 TAG=${1:-r02_c4}
@@ -24,12 +24,12 @@ if [ -z "${SKIP_STATS:-}" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o run -- python $R/bench.py --steps ${STEPS:-2} --warmup ${WARMUP:-0} $ARGS > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
   unset SLIM_GPU_TRACE
 fi
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in ${SKIP_PMC:+} $( [ -z "${SKIP_PMC:-}" ] && echo FETCH_SIZE WRITE_SIZE ); do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${TAG}_pmc_$c -o run -- python $R/bench.py --warmup 0 --steps 1 --cpu-seconds 0 $ARGS > $O/${TAG}_pmc_$c.json 2> $O/${TAG}_pmc_$c.err
   [ -f $O/cal_$c/cal_counter_collection.csv ] || rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/cal_$c -o cal -- $R/scripts/micro/gather_bw c > /dev/null 2>&1
 done
 cd $R
-python scripts/pmc_to_json.py $O/${TAG}_pmc_FETCH_SIZE/run_counter_collection.csv $O/${TAG}_pmc_WRITE_SIZE/run_counter_collection.csv \
+[ -n "${SKIP_PMC:-}" ] || python scripts/pmc_to_json.py $O/${TAG}_pmc_FETCH_SIZE/run_counter_collection.csv $O/${TAG}_pmc_WRITE_SIZE/run_counter_collection.csv \
   $O/cal_FETCH_SIZE/cal_counter_collection.csv $O/cal_WRITE_SIZE/cal_counter_collection.csv $O/${TAG}_pmc_FETCH_SIZE.json > $O/${TAG}_pmc_entry.json
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 grep trace $O/${TAG}_bench.err 2>/dev/null | cut -c1-400
