@@ -9,12 +9,14 @@ int main(int argc, char** argv) {
   const std::vector<OptSpec> specs = {
       {"ifmt", true},    {"binarize", false}, {"optTol", true},  {"niters", true},
       {"nnbrs", true},   {"simtype", true},   {"algo", true},    {"nthreads", true},
-      {"nrcmds", true},  {"dbglvl", true},    {"nomodels", false}, {"help", false}};
+      {"nrcmds", true},  {"dbglvl", true},    {"nomodels", false}, {"ngpus", true},
+      {"help", false}};
   Args a = parse_args(argc, argv, specs);
   if (a.has("help") || a.pos.size() != 3) {
     std::printf("\n Usage: slim_mselect [options] train-file test-file l12-file\n"
                 "   -ifmt=csr|csrnv|cluto|ijv  -binarize  -optTol=f  -niters=i  -nnbrs=i  -simtype=s\n"
-                "   -nrcmds=i  -nthreads=i  -dbglvl=i  -nomodels (do not write '<l1 l2>.model' files)\n\n");
+                "   -nrcmds=i  -nthreads=i  -dbglvl=i  -nomodels (do not write '<l1 l2>.model' files)\n"
+                "   -ngpus=i   (engine extension: R replicated on i GPUs, every model sharded over them)\n\n");
     return 0;
   }
   const Fmt fmt = parse_fmt(a.str("ifmt", "csr"));
@@ -40,6 +42,7 @@ int main(int argc, char** argv) {
   io[SLIM_OPTION_NTHREADS] = a.integer("nthreads", 1);
   io[SLIM_OPTION_MAXNITERS] = a.integer("niters", 10000);
   dopt[SLIM_OPTION_OPTTOL] = a.num("optTol", 1e-7);
+  if (a.has("ngpus")) io[SLIM_OPTION_GPU_NGPUS] = a.integer("ngpus", 1);
 
   int32_t status = SLIM_ERROR;
   slimgpu_matrix_t* R = SLIMGPU_MatrixFromHost(trn.nrows, trn.ptr.data(), trn.ind.data(),
