@@ -641,7 +641,8 @@ KernelFn pick_kernel(bool lds, bool has_val) {
 
 int round_up(int v, int q) { return (v + q - 1) / q * q; }
 
-constexpr int kBitmapBytes = 32 * 1024;  // dynamic LDS of a tile workgroup (user bitmap)
+constexpr int kBitmapBytes = 64 * 1024;  // dynamic LDS of a tile workgroup (user bitmap): two
+                                         // 8-wave workgroups per CU still fit (2 x (64 + 10) KB)
 
 }  // namespace
 
@@ -781,6 +782,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     if (use_tile) {
       int per_cu = 0;
       const size_t worst_lds = kBitmapBytes;
+      // (static + dynamic LDS beyond 64 KB needs the attribute)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)worst_lds));
       HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn),
                                                            64 * tileNW, worst_lds));
       if (per_cu < 1) {
