@@ -903,9 +903,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       // LDS user bitmap of the screen pass: one bit per 2^shift users of a member's range,
       // at most kBitmapBytes
       const int64_t range = (int64_t)(tile_r / (size_t)tileP);
+      auto words_at = [&](int sh) { return ((range >> sh) + 1 + 31) / 32; };
       bm_shift = 0;
-      while (((range >> bm_shift) + 31) / 32 * 4 > kBitmapBytes) ++bm_shift;
-      bm_words = (int)(((range >> bm_shift) + 1 + 31) / 32);
+      while (words_at(bm_shift) * 4 > kBitmapBytes) ++bm_shift;
+      bm_words = (int)words_at(bm_shift);
       if (opt.nnbrs > 0) bm_words = std::max(bm_words, tileP * 256);  // FSLIM's select histograms
     };
     // dynamic LDS of a tile workgroup: the user bitmap of the screen pass (FSLIM: the select
