@@ -261,6 +261,7 @@ int grid_for(int64_t n, int block, int cap_blocks) {
 }
 
 void pick_device(slimgpu_matrix* m, const LearnOptions& opt) {
+  (void)hipGetLastError();  // a failure of an earlier call must not be reported by this one
   int count = 0;
   HIP_TRY(hipGetDeviceCount(&count));
   if (count <= 0) throw HipError{hipErrorNoDevice, "hipGetDeviceCount"};
@@ -682,6 +683,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
   }
 
   try {
+    (void)hipGetLastError();
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t stream = m->stream;
     // One solve at a time per device and process: the tile kernel sizes its grid to the whole

@@ -256,6 +256,7 @@ int32_t evaluate_device(int32_t nusers, int32_t nrcmds, const int32_t* lists, co
   *out = EvalResult();
   if (nusers <= 0) return SLIM_OK;
   try {
+    (void)hipGetLastError();
     const int64_t tnnz = tst->rowptr[nusers];
     DevBuf<int32_t> d_lists((size_t)nusers * nrcmds), d_counts((size_t)nusers), d_tind((size_t)tnnz),
         d_fm((size_t)std::max(fm_ncols, 1)), d_n(3);
@@ -302,6 +303,7 @@ int32_t predict_1vsk_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t
   const int32_t nusers = hist->nrows;
   if (nusers <= 0) return SLIM_ERROR;
   try {
+    (void)hipGetLastError();
     const int64_t wnnz = W->rowptr[W->nrows], hnnz = hist->rowptr[nusers];
     DevBuf<int64_t> d_wptr((size_t)W->nrows + 1), d_hptr((size_t)nusers + 1);
     DevBuf<int32_t> d_wind((size_t)wnnz), d_hind((size_t)hnnz), d_neg((size_t)nusers * nnegs),

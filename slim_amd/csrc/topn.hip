@@ -512,6 +512,7 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
   const int64_t wnnz = W->rowptr[W->nrows], hnnz = hist->rowptr[nusers];
   const auto t_begin = std::chrono::steady_clock::now();
   try {
+    (void)hipGetLastError();  // a failure of an earlier call must not be reported by this one
     int ndev = 0;
     TOPN_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) throw HipFail{hipErrorNoDevice, "hipGetDeviceCount"};
@@ -565,7 +566,12 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
     if (const char* e = std::getenv("SLIM_TOPN_KEY")) key32 = key32 && std::atoi(e) != 64;
     const int pos_bits = key32 ? bits_for(max_row) : 32;
     const int item_bytes = key32 ? 8 : 12;
-    const int max_cw = kT2MaxCW * 12 * kT2Waves / (item_bytes * t2w) / 64 * 64;  // same LDS footprint
+    // chunk width: round 1's footprint (1536 ids x 12 bytes x 8 wavefronts), less whatever the
+    // merge area of this geometry needs beyond it, so that chunks + lists always fit the 160 KB
+    const size_t merge_bytes = (size_t)t2w * kT2MaxN * 16 + (size_t)t2w * sizeof(int) + 256;
+    const size_t chunk_bytes = std::min<size_t>((size_t)kT2MaxCW * 12 * kT2Waves,
+                                                (size_t)160 * 1024 - merge_bytes);
+    const int max_cw = (int)(chunk_bytes / ((size_t)item_bytes * t2w)) / 64 * 64;
     int cw = std::max(64, std::min(max_cw, ((ncols + t2w - 1) / t2w + 63) / 64 * 64));
     if (const char* e = std::getenv("SLIM_TOPN_CW")) {
       const int v = std::atoi(e);
