@@ -320,10 +320,14 @@ def kernel_hash():
     """Fingerprint of the solver sources: a PMC figure collected for another build of the
     kernels must not be reported for this one."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "slim_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "slim_amd", "csrc", name)) as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # comments and layout do not
+        text = re.sub(r"//[^\n]*", "", text)                       # change the machine code
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

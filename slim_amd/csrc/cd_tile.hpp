@@ -29,7 +29,12 @@
 //   * the last chunk of a column stays in registers between dot and update
 //     (store-only update); earlier chunks of long columns are re-read;
 //   * the next visit's scalars (column id, offsets, x row, norms) are loaded one
-//     visit ahead.
+//     visit ahead;
+//   * the screen aTy > l1 (estimate.c:412-444) is one extra pass a_i . y over every
+//     column for the P problems at once, each wavefront taking whole columns and
+//     skipping the users outside the tile's user set through an LDS bitmap -- no
+//     atomics, a fixed summation order (round 1 accumulated the Gram column with
+//     device-scope float atomics: twice the time, and order-dependent sums).
 //
 // Per problem the arithmetic is exactly that of cd_wave.hpp (and of the
 // reference, src/libslim/cd.c:101-142): same update rule, same epsilon rule,
@@ -52,8 +57,8 @@
 // until every tag shows the visit's epoch -- placement-independent, no fences; see
 // MI355X guide "R2").  Every member then evaluates the same updates on its own
 // copy of x, so members stay in lock-step without further communication.  All
-// spins are bounded: a member that waits longer than ~10 s raises the abort flag
-// and the launch ends with an error instead of hanging the GPU.
+// spins are bounded: a member that waits longer than ~10 s raises the abort flag,
+// the launch ends, and the host solves what is pending again without clusters.
 #pragma once
 #include <type_traits>
 
