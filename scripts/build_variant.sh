@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build variants/libslim_NAME.so from the current sources with extra compiler flags
 # (A/B runs of kernel experiments on one GPU box: SLIM_AMD_LIB=variants/libslim_NAME.so).
-# usage: scripts/build_variant.sh NAME "-DSLIM_TILE_ID_PIPE=0 ..."
+# usage: scripts/build_variant.sh NAME "-DSOME_EXPERIMENT=1 ..."   (any extra hipcc flags)
 set -e
 NAME=$1; FLAGS=$2
 R=$(cd "$(dirname "$0")/.." && pwd)
