@@ -89,7 +89,7 @@ __device__ __forceinline__ tile_gran_t gran_load(const tile_gran_t* p) {
 // phase is a template parameter so that the cluster geometry stays a function of kernel
 // arguments (re-derivable, no live registers across the visit loop).  Returns false when
 // the launch was aborted.
-template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM, bool WARM, bool HI>
+template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM, bool HI>
 __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& S, uint32_t& epoch) {
   constexpr int NT = 64 * NW;  // threads per workgroup
   constexpr int SL = 64 / P;       // users per wavefront step (lane groups)
@@ -425,7 +425,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 
     // -- warm start (estimate.c:453-464): previous coefficients of active coordinates
     // (in the FSLIM branch the reference never sets its warm-start flags: a no-op there)
-    const bool warm = WARM && !FSLIM && S.icolptr != nullptr;
+    const bool warm = S.icolptr != nullptr && !FSLIM;
     if (warm) {
 #pragma unroll
       for (int pp = 0; pp < PPW; ++pp) {
@@ -650,19 +650,13 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     };
 
     const uint64_t t_setup = wall_clock64();
-    if constexpr (WARM) {
-      // fold the warm-start coefficients into the residual (cd.c:108-110): one gather +
-      // write-back pass over every column with a coefficient beyond 1e-7 (visit, mode 1).  A
-      // row-wise form (one wavefront per user gathering the x lines of its row) was measured
-      // and is slower: 71 against 66 s per warm-started C5 grid step.
-      if (warm) {
-        float unused = 0.0f;
-        for (int p = 0; p < nunion; ++p) {
-          const int i = uni(ul[p]);
-          const int64_t* sp = csplit + (int64_t)i * (K + 1);
-          visit(i, uni(sp[mk]), uni(sp[mk + 1]), uni(sp[K]) - uni(sp[0]), x[(int64_t)i * P + q],
-                0.0f, 0.0f, !done_q, unused, 1, 0, 0);
-        }
+    if (warm) {
+      float unused = 0.0f;
+      for (int p = 0; p < nunion; ++p) {
+        const int i = uni(ul[p]);
+        const int64_t* sp = csplit + (int64_t)i * (K + 1);
+        visit(i, uni(sp[mk]), uni(sp[mk + 1]), uni(sp[K]) - uni(sp[0]), x[(int64_t)i * P + q],
+              0.0f, 0.0f, !done_q, unused, 1, 0, 0);
       }
     }
 
@@ -817,23 +811,21 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 // -- gather / barrier / cluster exchange / write-back -- then overlap).
 // (16 wavefronts per CU either way: the second launch bound, 4 waves per SIMD, caps the
 // kernel at 128 VGPRs)
-// FSLIM (neighbour selection instead of the l1 screen) and WARM (a previous model folded into
-// the residual before the sweeps) are separate instantiations: the visit loop sits at the
-// 128-VGPR cap, and code that merely exists in the same kernel costs it 5 % (the FSLIM block)
-// to 8 % (the warm-start fold, a second inlined copy of the visit) -- measured same-box on C4,
-// profiles/r02/ab_variants.txt; the same runs rejected parking a chunk of a visit in LDS,
-// pipelining the id loads of a visit's chunks, an 8-wavefront / 256-VGPR form of the
-// workgroup, and a row-wise form of the fold.
-template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM = false, bool WARM = false>
+// FSLIM (neighbour selection instead of the l1 screen) is a separate instantiation: the visit
+// loop sits at the 128-VGPR cap, and code that merely exists in the same kernel costs it 5 %
+// (measured same-box on C4, profiles/r02/ab_variants.txt; the same runs rejected parking a
+// chunk of a visit in LDS, pipelining the id loads of a visit's chunks, and an 8-wavefront /
+// 256-VGPR form of the workgroup).
+template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM = false>
 __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
   uint32_t epoch = 0;
   // heavy phase first: whole clusters of S.cluster_hi only (S.cluster divides S.cluster_hi,
   // so the workgroups of a big cluster regroup into whole small ones afterwards)
   if (S.nheavy > 0 && (int)blockIdx.x < ((int)gridDim.x / S.cluster_hi) * S.cluster_hi) {
-    if (!tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, WARM, true>(A, S, epoch)) return;
+    if (!tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, true>(A, S, epoch)) return;
     __syncthreads();
   }
-  tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, WARM, false>(A, S, epoch);
+  tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, false>(A, S, epoch);
 }
 
 }  // namespace slimamd

@@ -755,11 +755,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     if (use_tile) {
       const bool prof = trace_level >= 2;
       const bool val = !m->binary;
-      const bool warm_start = imodel && imodel->colptr && imodel->ncols > 0;
       if (tileP == 32 && opt.nnbrs > 0)
         fn = tile_kernel_p32_fslim(val, tileNW == 16);
-      else if (tileP == 32 && warm_start)  // (a profile run of a warm start: unprofiled)
-        fn = tile_kernel_p32_warm(val, tileNW == 16);
       else if (tileP == 32)
         fn = tileNW == 16 ? tile_kernel_p32_nw16(val, prof) : tile_kernel_p32_nw8(val, prof);
       else

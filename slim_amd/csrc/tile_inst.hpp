@@ -1,8 +1,7 @@
 // tile_inst.hpp -- the instantiations of cd_tile_kernel, a few per translation unit so that
 // they compile side by side (`make -j`); engine.hip picks one through tile_kernel().
 //   base : <P, HAS_VAL, PROFILE, NW>                       P in {32, 16}, NW in {16, 8}
-//   FSLIM: <32, HAS_VAL, false, NW, true>          WARM: <32, HAS_VAL, false, NW, false, true>
-//   (16-wide tiles -- more than 33M users -- are always WARM-capable)
+//   FSLIM: <32, HAS_VAL, false, NW, true>
 #pragma once
 #include "cd_tile.hpp"
 
@@ -16,15 +15,13 @@ KernelFn tile_kernel_p16_nw16(bool has_val, bool profile);
 KernelFn tile_kernel_p16_nw8(bool has_val, bool profile);
 // P = 32 only: neighbour selection instead of the l1 screen (FSLIM)
 KernelFn tile_kernel_p32_fslim(bool has_val, bool nw16);
-// P = 32 only: with the warm-start fold (a previous model given)
-KernelFn tile_kernel_p32_warm(bool has_val, bool nw16);
 
-#define SLIM_TILE_INSTANTIATE(NAME, PP, NWW)                                                   \
-  KernelFn NAME(bool has_val, bool profile) {                                                   \
-    return has_val ? (profile ? cd_tile_kernel<PP, true, true, NWW, false, PP == 16>            \
-                              : cd_tile_kernel<PP, true, false, NWW, false, PP == 16>)          \
-                   : (profile ? cd_tile_kernel<PP, false, true, NWW, false, PP == 16>           \
-                              : cd_tile_kernel<PP, false, false, NWW, false, PP == 16>);        \
+#define SLIM_TILE_INSTANTIATE(NAME, PP, NWW)                                        \
+  KernelFn NAME(bool has_val, bool profile) {                                        \
+    return has_val ? (profile ? cd_tile_kernel<PP, true, true, NWW>                  \
+                              : cd_tile_kernel<PP, true, false, NWW>)                \
+                   : (profile ? cd_tile_kernel<PP, false, true, NWW>                 \
+                              : cd_tile_kernel<PP, false, false, NWW>);              \
   }
 
 }  // namespace slimamd
