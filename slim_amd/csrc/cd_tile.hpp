@@ -811,11 +811,12 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 // -- gather / barrier / cluster exchange / write-back -- then overlap).
 // (16 wavefronts per CU either way: the second launch bound, 4 waves per SIMD, caps the
 // kernel at 128 VGPRs)
-// FSLIM (neighbour selection instead of the l1 screen) is a separate instantiation: the visit
-// loop sits at the 128-VGPR cap, and code that merely exists in the same kernel costs it 5 %
-// (measured same-box on C4, profiles/r02/ab_variants.txt; the same runs rejected parking a
-// chunk of a visit in LDS, pipelining the id loads of a visit's chunks, and an 8-wavefront /
-// 256-VGPR form of the workgroup).
+// FSLIM (neighbour selection instead of the l1 screen) is a separate instantiation: it needs
+// 32 KB of LDS for its select histograms whatever the matrix, and the visit loop sits at the
+// 128-VGPR cap, where more code in the kernel is not free.  (Same-box A/B runs,
+// profiles/r02/ab_variants.txt, rejected parking a chunk of a visit in LDS, pipelining the id
+// loads of a visit's chunks, an 8-wavefront / 256-VGPR form of the workgroup and a row-wise
+// warm-start fold.)
 template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM = false>
 __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
   uint32_t epoch = 0;
