@@ -144,6 +144,7 @@ bool broadcast_csr_rccl(const std::vector<int>& devs, int32_t nrows, const ssize
       if (pt.bytes == 0) continue;
       nc.GroupStart();
       for (size_t d = 0; d < n; ++d) {
+        (void)hipSetDevice(devs[d]);  // (older RCCL wants the current device to match the comm)
         void* buf = pt.which == 0 ? (void*)(*out)[d].rowptr
                                   : pt.which == 1 ? (void*)(*out)[d].rowind : (void*)(*out)[d].rowval;
         if (nc.Broadcast(buf, buf, pt.bytes, /*ncclInt8*/ 0, /*root*/ 0, comms[d], streams[d]) != 0) ok = false;
