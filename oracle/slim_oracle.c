@@ -946,6 +946,124 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
   return ncols;
 }
 
+/* ------------------------------------------------------------------------ */
+/* EstimateModelADMM (estimate.c:38-304; MKL-only in the reference)           */
+/* ------------------------------------------------------------------------ */
+/* Plain-loop restatement in the reference's precision and operation order where it is
+ * observable: T = R^T R, P = (T + (l2 + rho) I)^-1 by Cholesky (dpotrf / dpotri,
+ * estimate.c:150-163), A = P T, then 30 iterations of estimate.c:166-213 with rho = 1e4.
+ * The products are naive triple loops (k ascending), so they differ from a BLAS by the
+ * summation order only.  Returns W's row view (positive entries, float values).
+ * Parity note: the reference ships no output of this path (it needs MKL) -- unpinned.      */
+int32_t oracle_learn_admm(int32_t nrows, const int64_t *rowptr, const int32_t *rowind,
+                          const float *rowval, double l1r, double l2r, int32_t nthreads,
+                          int64_t **r_rowptr, int32_t **r_rowind, float **r_rowval) {
+  const int64_t nnz = rowptr[nrows];
+  const int32_t m = oracle_ncols(nnz, rowind);
+  if (m <= 0) return -1;
+  const double RHO = 10000.0;
+  const int MAXITERS = 30;
+  const size_t n2 = (size_t)m * (size_t)m;
+  double *T = (double *)calloc(n2, sizeof(double)), *A = (double *)calloc(n2, sizeof(double));
+  double *B = (double *)calloc(n2, sizeof(double)), *W = (double *)calloc(n2, sizeof(double));
+  double *C = (double *)calloc(n2, sizeof(double)), *P = (double *)calloc(n2, sizeof(double));
+  double *L = (double *)calloc(n2, sizeof(double)), *Li = (double *)calloc(n2, sizeof(double));
+  double *gamma = (double *)calloc((size_t)m, sizeof(double));
+  if (nthreads < 1) nthreads = 1;
+  /* T = Rt R (estimate.c:124-125) */
+  for (int32_t u = 0; u < nrows; u++)
+    for (int64_t a = rowptr[u]; a < rowptr[u + 1]; a++)
+      for (int64_t b = rowptr[u]; b < rowptr[u + 1]; b++)
+        T[(size_t)rowind[a] * m + rowind[b]] +=
+            (double)(rowval ? rowval[a] : 1.0f) * (double)(rowval ? rowval[b] : 1.0f);
+  /* P = T + (l2 + rho) I, Cholesky P = L L^T, P^-1 = L^-T L^-1 */
+  for (size_t k = 0; k < n2; k++) P[k] = T[k];
+  for (int32_t i = 0; i < m; i++) P[(size_t)i * m + i] += l2r + RHO;
+  for (int32_t j = 0; j < m; j++) {
+    double d = P[(size_t)j * m + j];
+    for (int32_t k = 0; k < j; k++) d -= L[(size_t)j * m + k] * L[(size_t)j * m + k];
+    if (d <= 0.0) return -2;
+    d = sqrt(d);
+    L[(size_t)j * m + j] = d;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int32_t i = j + 1; i < m; i++) {
+      double v = P[(size_t)i * m + j];
+      for (int32_t k = 0; k < j; k++) v -= L[(size_t)i * m + k] * L[(size_t)j * m + k];
+      L[(size_t)i * m + j] = v / d;
+    }
+  }
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 8)
+  for (int32_t c = 0; c < m; c++) { /* column c of L^-1 by forward substitution */
+    for (int32_t i = c; i < m; i++) {
+      double v = i == c ? 1.0 : 0.0;
+      for (int32_t k = c; k < i; k++) v -= L[(size_t)i * m + k] * Li[(size_t)k * m + c];
+      Li[(size_t)i * m + c] = v / L[(size_t)i * m + i];
+    }
+  }
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 8)
+  for (int32_t i = 0; i < m; i++) /* P^-1 = Li^T Li */
+    for (int32_t j = 0; j <= i; j++) {
+      double v = 0.0;
+      for (int32_t k = i; k < m; k++) v += Li[(size_t)k * m + i] * Li[(size_t)k * m + j];
+      P[(size_t)i * m + j] = P[(size_t)j * m + i] = v;
+    }
+  /* A = P T (estimate.c:166-167) */
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (int32_t i = 0; i < m; i++)
+    for (int32_t k = 0; k < m; k++) {
+      const double p = P[(size_t)i * m + k];
+      for (int32_t j = 0; j < m; j++) A[(size_t)i * m + j] += p * T[(size_t)k * m + j];
+    }
+  const double irho = 1.0 / RHO, kappa = l1r / RHO;
+  for (int iter = 0; iter < MAXITERS; iter++) { /* estimate.c:169-213 */
+    for (size_t k = 0; k < n2; k++) W[k] = RHO * W[k];
+    for (size_t k = 0; k < n2; k++) W[k] = W[k] - C[k];
+    memset(T, 0, sizeof(double) * n2);
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int32_t i = 0; i < m; i++)
+      for (int32_t k = 0; k < m; k++) {
+        const double p = P[(size_t)i * m + k];
+        for (int32_t j = 0; j < m; j++) T[(size_t)i * m + j] += p * W[(size_t)k * m + j];
+      }
+    for (size_t k = 0; k < n2; k++) T[k] = T[k] + A[k];
+    for (int32_t i = 0; i < m; i++) gamma[i] = T[(size_t)i * m + i] / P[(size_t)i * m + i];
+    for (int32_t i = 0; i < m; i++)
+      for (int32_t j = 0; j < m; j++) B[(size_t)i * m + j] = -1.0 * P[(size_t)i * m + j] * gamma[j];
+    for (size_t k = 0; k < n2; k++) B[k] = B[k] + T[k];
+    for (size_t k = 0; k < n2; k++) {
+      const double alpha = B[k] + irho * C[k];
+      const double hi = alpha - kappa > 0.0 ? alpha - kappa : 0.0;
+      const double lo = -alpha - kappa > 0.0 ? -alpha - kappa : 0.0;
+      const double temp = hi - lo;
+      W[k] = temp > 0.0 ? temp : 0.0;
+    }
+    for (size_t k = 0; k < n2; k++) B[k] = B[k] - W[k];
+    for (size_t k = 0; k < n2; k++) B[k] = RHO * B[k];
+    for (size_t k = 0; k < n2; k++) C[k] = C[k] + B[k];
+  }
+  int64_t cnt = 0;
+  for (size_t k = 0; k < n2; k++) cnt += W[k] > 0.0;
+  int64_t *wptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)m + 1));
+  int32_t *wind = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cnt ? cnt : 1));
+  float *wval = (float *)malloc(sizeof(float) * (size_t)(cnt ? cnt : 1));
+  cnt = 0;
+  wptr[0] = 0;
+  for (int32_t i = 0; i < m; i++) { /* estimate.c:228-262 */
+    for (int32_t j = 0; j < m; j++)
+      if (W[(size_t)i * m + j] > 0.0) {
+        wind[cnt] = j;
+        wval[cnt] = (float)W[(size_t)i * m + j];
+        cnt++;
+      }
+    wptr[i + 1] = cnt;
+  }
+  free(T); free(A); free(B); free(W); free(C); free(P); free(L); free(Li); free(gamma);
+  *r_rowptr = wptr;
+  *r_rowind = wind;
+  *r_rowval = wval;
+  return m;
+}
+
 void oracle_free(void *p) { free(p); }
 
 /* ------------------------------------------------------------------------ */

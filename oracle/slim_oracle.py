@@ -180,6 +180,27 @@ def learn_cd_tile(R, tileP=32, order=None, l1r=1.0, l2r=1.0, optTol=1e-7, maxnit
     return W
 
 
+def learn_admm(R, l1r=1.0, l2r=1.0, nthreads=1, binary=False):
+    """EstimateModelADMM restated (estimate.c:38-304).  Returns W as scipy CSR (the model's row
+    view: W[i, k] = weight of history item i when scoring candidate k)."""
+    L = lib()
+    nrows, ptr, ind, val = _csr_arrays(R, binary)
+    wptr, wind, wval = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_float)()
+    L.oracle_learn_admm.restype = C.c_int32
+    n = L.oracle_learn_admm(C.c_int32(nrows), _p(ptr, C.c_int64), _p(ind, C.c_int32),
+                            _p(val, C.c_float), C.c_double(l1r), C.c_double(l2r),
+                            C.c_int32(nthreads), C.byref(wptr), C.byref(wind), C.byref(wval))
+    if n < 0:
+        raise RuntimeError("oracle_learn_admm failed (%d)" % n)
+    indptr = np.ctypeslib.as_array(wptr, shape=(n + 1,)).copy()
+    nnz = int(indptr[-1])
+    indices = np.ctypeslib.as_array(wind, shape=(max(nnz, 1),))[:nnz].copy()
+    data = np.ctypeslib.as_array(wval, shape=(max(nnz, 1),))[:nnz].copy()
+    for q in (wptr, wind, wval):
+        L.oracle_free(C.cast(q, C.c_void_p))
+    return sp.csr_matrix((data, indices, indptr), shape=(n, n))
+
+
 def _w_rows(W):
     Wr = sp.csr_matrix(W)
     Wr.sort_indices()

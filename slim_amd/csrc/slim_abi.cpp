@@ -27,9 +27,10 @@ slim_csr_t* learn_from_host(int32_t nrows, const ssize_t* rowptr, const int32_t*
                             const slim_csr_t* imodel, int32_t* status) {
   set_error("");
   LearnOptions opt = decode_options(ioptions, doptions);
-  if (opt.algo != SLIM_ALGO_CD) {
-    // reference: ADMM needs MKL and otherwise exits (estimate.c:309-317)
-    set_error("only algo=cd (coordinate descent) is implemented by this engine");
+  if (opt.algo == SLIM_ALGO_ADMM)  // estimate.c:38-304 (MKL-only in the reference): admm.hip
+    return learn_admm(nrows, rowptr, rowind, rowval, opt, status);
+  if (opt.algo != SLIM_ALGO_CD) {  // api.c:81-84 prints "Algorithm not supported" and exits
+    set_error("unknown algorithm: algo must be cd (coordinate descent) or admm");
     *status = SLIM_ERROR_INPUT;
     return nullptr;
   }
@@ -184,10 +185,11 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
   LearnOptions base = decode_options(ioptions, doptions);
   const int32_t nrcmds =
       (!ioptions || ioptions[SLIM_OPTION_NRCMDS] == -1) ? 10 : ioptions[SLIM_OPTION_NRCMDS];
-  if (base.algo != SLIM_ALGO_CD) {
-    set_error("Py_SLIM_Mselect: only algo=cd is implemented by this engine");
+  if (base.algo != SLIM_ALGO_CD && base.algo != SLIM_ALGO_ADMM) {
+    set_error("Py_SLIM_Mselect: unknown algorithm");
     return SLIM_ERROR_INPUT;
   }
+  const bool admm = base.algo == SLIM_ALGO_ADMM;
 
   // R goes to HBM once for the whole grid (the reference re-runs
   // CreateTrainingMatrix inside every SLIM_Learn call, pyapi.c:295-297)
@@ -195,8 +197,8 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
   if (ioptions == nullptr || ioptions[SLIM_OPTION_GPU_NGPUS] == -1)
     if (const char* e = std::getenv("SLIM_GPU_NGPUS")) base.ngpus = std::max(1, std::atoi(e));
   slimgpu_matrix_t* mat =
-      multi_from_host(trn->nrows, trn->rowptr, trn->rowind, trn->rowval, base, &status);
-  if (!mat) return status;
+      admm ? nullptr : multi_from_host(trn->nrows, trn->rowptr, trn->rowind, trn->rowval, base, &status);
+  if (!mat && !admm) return status;
 
   const int32_t trn_ncols = max_index_plus_one(trn->rowptr[trn->nrows], trn->rowind);
   const int32_t tst_ncols = max_index_plus_one(tst->rowptr[tst->nrows], tst->rowind);
@@ -224,7 +226,9 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
       opt.l1r = arrayl1[a];
       opt.l2r = arrayl2[b];
       slim_csr_t* prev = model;  // warm start from the previous cell
-      model = multi_learn(mat, opt, prev, &status);
+      // (ADMM ignores the previous model, estimate.c:38)
+      model = admm ? learn_admm(trn->nrows, trn->rowptr, trn->rowind, trn->rowval, opt, &status)
+                   : multi_learn(mat, opt, prev, &status);
       csr_free(prev);
       if (!model) {
         rc = status;

@@ -230,8 +230,15 @@ def test_training_fails_loudly_without_a_gpu(ml100k):
 
 
 def test_unsupported_algorithms_are_input_errors(ml100k):
-    from slim_amd import SLIM, SLIMatrix
+    """api.c:81-84 prints "Algorithm not supported" and exits; here: SLIM_ERROR_INPUT."""
+    lib = _lib.load()
     R, _ = ml100k
-    with pytest.raises(RuntimeError):
-        SLIM().train({"algo": "admm"}, SLIMatrix(R))
-    assert "only algo=cd" in _lib.last_error()
+    io = np.full(SLIM_NOPTIONS, -1, np.int32)
+    io[5] = 7                                       # SLIM_OPTION_ALGO: neither admm (0) nor cd (1)
+    st = C.c_int32(0)
+    val = np.ascontiguousarray(R.data, np.float32)
+    h = lib.SLIM_Learn(R.shape[0], np.ascontiguousarray(R.indptr, np.intp),
+                       np.ascontiguousarray(R.indices, np.int32), val.ctypes.data_as(C.c_void_p),
+                       io.ctypes.data_as(C.c_void_p), None, None, C.byref(st))
+    assert not h and st.value == -2
+    assert "unknown algorithm" in _lib.last_error()

@@ -853,3 +853,38 @@ def test_gpu_1vsk_matches_oracle(ml100k, ml_gpu):
             assert np.array_equal(sc.reshape(nu, n), sc_o), (nnegs, n, env)
     lib.Py_csr_free(hr)
     lib.SLIM_FreeModel(C.byref(hm))
+
+
+# ---- SURVEY 8(f), last row: ADMM ---------------------------------------------------------------
+def test_admm_matches_oracle(ml100k, automotive, capfd):
+    """SLIM_Learn(algo = admm) -- estimate.c:38-304, MKL-only in the reference -- on the GPU
+    (rocSOLVER factorisation, rocBLAS products, fused HIP kernels for the iteration) against the
+    oracle's plain-loop restatement: fp64 throughout, so only the summation order of the products
+    differs.  Through the C ABI, the Python mirror and the CLI option."""
+    lib = _lib.load()
+    for R, l1, l2 in ((sp.csr_matrix(ml100k[0][:, :600]), 1.0, 1.0), (sp.csr_matrix(automotive[0]), 2.0, 0.5)):
+        R.sort_indices()
+        io = np.full(SLIM_NOPTIONS, -1, np.int32)
+        do = np.full(SLIM_NOPTIONS, -1.0, np.float64)
+        io[Opt.ALGO] = 0
+        do[Opt.L1R], do[Opt.L2R] = l1, l2
+        st = C.c_int32(0)
+        h = lib.SLIM_Learn(R.shape[0], R.indptr.astype(np.intp), R.indices.astype(np.int32),
+                           R.data.astype(np.float32).ctypes.data_as(C.c_void_p),
+                           io.ctypes.data_as(C.c_void_p), do.ctypes.data_as(C.c_void_p), None,
+                           C.byref(st))
+        assert h and st.value == SLIM_OK, _lib.last_error()
+        from slim_amd.engine import model_to_scipy
+        W = sp.csr_matrix(model_to_scipy(lib, h))           # column view -> same matrix
+        Wo = O.learn_admm(R, l1r=l1, l2r=l2, nthreads=8)
+        assert W.shape == Wo.shape
+        assert maxdiff(W, Wo) <= 1e-6
+        assert abs(W.nnz - Wo.nnz) <= max(4, Wo.nnz // 10000)   # entries at the edge of > 0
+        assert W.diagonal().max() <= 1e-3 and W.data.min() > 0
+    assert "Learning the model using ADMM" in capfd.readouterr().out
+    # the Python mirror: train + predict
+    trn = SLIMatrix(sp.csr_matrix(ml100k[0][:, :600]))
+    model = SLIM()
+    model.train({"algo": "admm", "l1r": 1.0, "l2r": 1.0}, trn)
+    out = model.predict(trn, nrcmds=5)
+    assert len(out) > 0

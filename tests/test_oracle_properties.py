@@ -72,3 +72,34 @@ def test_oracle_topn_matches_dense_scores():
         assert len(got) == len(want)
         # same scores (ids may swap only where two scores tie to fp32 rounding)
         assert np.allclose(sorted(S[u, got], reverse=True), sorted(S[u, want], reverse=True), atol=1e-5)
+
+
+def test_oracle_admm_against_a_numpy_restatement():
+    """EstimateModelADMM (estimate.c:38-304) restated twice: the oracle's plain C loops and, here,
+    numpy with LAPACK for the inverse and BLAS for the products -- two independent routes through
+    the same recurrences must agree to rounding; plus what the iteration guarantees by
+    construction (W >= 0, and a diagonal driven towards zero by gamma)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2)
+    R = sp.random(500, 120, density=0.08, random_state=rng, format="csr", dtype=np.float32)
+    R.data = rng.integers(1, 6, R.nnz).astype(np.float32)
+    l1, l2, rho = 0.7, 2.0, 10000.0
+    W = O.learn_admm(R, l1r=l1, l2r=l2, nthreads=4).toarray().astype(np.float64)
+    Rd = R.toarray().astype(np.float64)
+    T = Rd.T @ Rd
+    m = T.shape[0]
+    P = np.linalg.inv(T + (l2 + rho) * np.eye(m))
+    A = P @ T
+    Wn = np.zeros((m, m))
+    Cn = np.zeros((m, m))
+    for _ in range(30):
+        Wn = rho * Wn - Cn
+        Tn = P @ Wn + A
+        gamma = np.diag(Tn) / np.diag(P)
+        B = Tn - P * gamma[None, :]
+        alpha = B + Cn / rho
+        Wn = np.maximum(np.maximum(alpha - l1 / rho, 0) - np.maximum(-alpha - l1 / rho, 0), 0)
+        Cn = Cn + rho * (B - Wn)
+    assert np.abs(W - Wn.astype(np.float32)).max() <= 1e-6
+    assert W.min() >= 0 and np.abs(np.diag(W)).max() <= 1e-3
+    assert (W > 0).sum() > m
