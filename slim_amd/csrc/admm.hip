@@ -223,6 +223,7 @@ slim_csr_t* learn_admm(int32_t nrows, const ssize_t* rowptr, const int32_t* rowi
     if (rowind[k] < 0) return fail(SLIM_ERROR_INPUT, "SLIM_Learn(admm): negative item id");
   const int64_t n2 = (int64_t)m * m;
   std::printf("Learning the model using ADMM... \n");  // estimate.c:41
+  std::fflush(stdout);
   try {
     (void)hipGetLastError();
     int ndev = 0;
