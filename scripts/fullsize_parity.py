@@ -104,19 +104,22 @@ def main():
         if args.noise:
             t0 = time.time()
             Wp = O.learn_cd(R, cols=tile, order=O.ORDER_PERM, seed=args.seed, aty=O.ATY_GRAM,
-                            maxniters=10000, nthreads=threads, binary=True, **kw)
+                            maxniters=10000, nthreads=threads, binary=True, chunk=1, **kw)
             out["oracle_perm_s"] = round(time.time() - t0, 1)
             out["noise_oracle_tile_vs_perm"] = maxdiff(Wo[:, tile], Wp[:, tile])
             out["max_abs_dW_gpu_vs_perm"] = maxdiff(W[:, tile], Wp[:, tile])
             Wl = O.learn_cd(R, cols=tile, order=O.ORDER_LOCAL, seed=args.seed + 7, aty=O.ATY_GRAM,
-                            maxniters=10000, nthreads=threads, binary=True, **kw)
+                            maxniters=10000, nthreads=threads, binary=True, chunk=1, **kw)
             out["noise_oracle_perm_vs_local"] = maxdiff(Wl[:, tile], Wp[:, tile])
             print(json.dumps(out), flush=True)
         if args.tight:
             kt = dict(l1r=1.0, l2r=1.0, optTol=1e-12)
             Wt, _ = mat.learn(columns=tile, niters=100000, seed=args.seed, **kt)
+            t0 = time.time()
             Wpt = O.learn_cd(R, cols=tile, order=O.ORDER_PERM, seed=args.seed, aty=O.ATY_GRAM,
-                             maxniters=100000, nthreads=threads, binary=True, **kt)
+                             maxniters=100000, nthreads=threads, binary=True, chunk=1, **kt)
+            out["tight_oracle_s"] = round(time.time() - t0, 1)
+            out["tight_gpu_sweeps_max"] = int(mat.column_stats().sweeps[tile].max())
             out["tight_max_abs_dW_gpu_vs_perm"] = maxdiff(Wt[:, tile], Wpt[:, tile])
             print(json.dumps(out), flush=True)
     mat.close()
