@@ -60,6 +60,16 @@ def _check_tile(mat, R, tile, threads, **geom):
     return W, Wo, st
 
 
+def _check_tile_tight(mat, R, tile, threads):
+    """at optTol 1e-12 the visiting order no longer matters -- the tile kernel
+    against the oracle in its own per-item order (reference arithmetic), <= 2e-5."""
+    kt = dict(l1r=1.0, l2r=1.0, optTol=1e-12)
+    Wt, _ = mat.learn(columns=tile, niters=100000, seed=1, **kt)
+    Wp = O.learn_cd(R, cols=tile, order=O.ORDER_PERM, seed=1, aty=O.ATY_GRAM, maxniters=100000,
+                    nthreads=threads, binary=True, chunk=1, **kt)
+    assert maxdiff(Wt[:, tile], Wp[:, tile]) <= 2e-5                # observed 2.6e-8 / 1.0e-7
+
+
 @pytest.mark.timeout(900, method="thread")
 def test_c4_full_size_tiles_match_oracle_in_tile_order():
     """C4, seed 1: the median tile of the benchmark's first step, the tile holding the first column
@@ -74,6 +84,7 @@ def test_c4_full_size_tiles_match_oracle_in_tile_order():
     sampled = int(np.where(tiles == c0)[0][0])
     picked = [tiles[len(tiles) // 2], tiles[sampled]]
     results = [_check_tile(mat, R, t, threads) for t in picked]      # one tile: clusters of 16
+    _check_tile_tight(mat, R, picked[0], threads)
     # both tiles in one launch, the first one as a "heavy" tile on a cluster of 16, the second
     # on clusters of 4: the per-problem arithmetic and the visiting order may not depend on it
     both = np.concatenate(picked)
@@ -94,5 +105,8 @@ def test_c5_full_size_tile_matches_oracle_in_tile_order():
     mat, R = _stage("c5")
     threads = min(32, O.max_threads())
     tiles = _batch_tiles(mat, 0, 4096)
+    O.cache_setup(True)
     _check_tile(mat, R, tiles[len(tiles) // 2], threads)
+    _check_tile_tight(mat, R, tiles[len(tiles) // 2], threads)
+    O.cache_setup(False)
     mat.close()
