@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -236,12 +237,11 @@ slim_csr_t* learn_admm(int32_t nrows, const ssize_t* rowptr, const int32_t* rowi
       return fail(SLIM_ERROR_MEMORY, "SLIM_Learn(admm): six " + std::to_string(m) + " x " +
                                          std::to_string(m) + " fp64 matrices do not fit this GPU");
     static DenseLibs libs;
+    static std::once_flag once;
     static bool loaded = false;
-    std::string err;
-    if (!loaded) {
-      if (!libs.load(&err)) return fail(SLIM_ERROR, "SLIM_Learn: " + err);
-      loaded = true;
-    }
+    static std::string load_err;
+    std::call_once(once, [&]() { loaded = libs.load(&load_err); });
+    if (!loaded) return fail(SLIM_ERROR, "SLIM_Learn: " + load_err);
     hipDeviceProp_t prop;
     int dev = 0;
     ADMM_TRY(hipGetDevice(&dev));
