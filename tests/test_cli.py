@@ -137,3 +137,18 @@ def test_mselect_l12file(tmp_path):
     assert os.path.exists(str(tmp_path / "1.0 1.0.model"))   # slim_mselect.c:110-112
     nnz = [int(r[2]) for r in rows]
     assert nnz[0] > nnz[1] > nnz[2]                          # more l1 => sparser model
+
+
+@pytest.mark.gpu
+def test_learn_admm_then_predict_ml100k(tmp_path):
+    """slim_learn -algo=admm (the reference needs an MKL build for it, cmdline_learn.c:25): the
+    model scores like the figures of profiles/r02/admm_ml100k.txt."""
+    mdl = str(tmp_path / "admm.model")
+    p = run("slim_learn", "-algo=admm", "-l1r=1", "-l2r=1", os.path.join(GOLDEN, "ml100k-train.csr"), mdl)
+    assert "solver: admm" in p.stdout and "Learning the model using ADMM" in p.stdout
+    W = read_csr_text(mdl)
+    assert W.shape[0] == 1683 and W.nnz > 100000 and W.data.min() > 0
+    q = run("slim_predict", mdl, os.path.join(GOLDEN, "ml100k-train.csr"),
+            os.path.join(GOLDEN, "ml100k-test.csr"))
+    hr = float(re.search(r"hr: (\S+)", q.stdout).group(1))
+    assert 0.31 <= hr <= 0.34                                     # 0.3266 measured
