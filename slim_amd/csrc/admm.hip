@@ -9,9 +9,12 @@
 // here.  Everything is dense m x m, so this is the one GEMM-shaped corner of the library:
 //   * R^T R: one wavefront per user row, fp64 atomics into T (hand-written; exact for integer
 //     ratings, order-independent to 1e-16 otherwise);
-//   * Cholesky + inverse: rocSOLVER dpotrf / dpotri, the products P T and P W: rocBLAS dgemm
-//     (fp64 MFMA) -- plain library calls, loaded on demand (dlopen) so that the CD path does
-//     not pay for them;
+//   * Cholesky + inverse (the reference: LAPACKE_dpotrf / dpotri, estimate.c:150-155): a blocked
+//     right-looking factorisation -- the 64 x 64 diagonal blocks by a hand-written one-workgroup
+//     kernel in LDS, the panel solve and the trailing update by rocBLAS dtrsm / dsyrk -- then
+//     L^-1 by dtrsm and P^-1 = L^-T L^-1 by dgemm; the products P T and P W: rocBLAS dgemm (fp64
+//     MFMA).  Plain library calls, rocBLAS only (loaded on demand with dlopen, so the CD path
+//     does not pay for it; rocSOLVER's 888 MB shared object is not needed at all);
 //   * everything elementwise (the whole iteration except the product) is one fused kernel with
 //     the reference's rounding sequence (separate multiplies and adds, no contraction), plus a
 //     m-thread kernel for gamma;
@@ -23,6 +26,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -57,38 +61,40 @@ struct DevBuf {
 // ---- the two libraries, resolved at first use ------------------------------------------
 struct DenseLibs {
   void* blas = nullptr;
-  void* solver = nullptr;
   int (*create_handle)(void**) = nullptr;
   int (*destroy_handle)(void*) = nullptr;
   int (*set_stream)(void*, hipStream_t) = nullptr;
   int (*dgemm)(void*, int, int, int, int, int, const double*, const double*, int, const double*,
                int, const double*, double*, int) = nullptr;
-  int (*dpotrf)(void*, int, int, double*, int, int*) = nullptr;
-  int (*dpotri)(void*, int, int, double*, int, int*) = nullptr;
+  int (*dtrsm)(void*, int, int, int, int, int, int, const double*, const double*, int, double*,
+               int) = nullptr;
+  int (*dsyrk)(void*, int, int, int, int, const double*, const double*, int, const double*,
+               double*, int) = nullptr;
   bool load(std::string* err) {
     blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
     if (!blas) blas = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
-    solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!solver) solver = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
-    if (!blas || !solver) {
-      *err = "algo=admm needs librocblas.so and librocsolver.so (not found)";
+    if (!blas) {
+      *err = "algo=admm needs librocblas.so (not found)";
       return false;
     }
     create_handle = reinterpret_cast<decltype(create_handle)>(dlsym(blas, "rocblas_create_handle"));
     destroy_handle = reinterpret_cast<decltype(destroy_handle)>(dlsym(blas, "rocblas_destroy_handle"));
     set_stream = reinterpret_cast<decltype(set_stream)>(dlsym(blas, "rocblas_set_stream"));
     dgemm = reinterpret_cast<decltype(dgemm)>(dlsym(blas, "rocblas_dgemm"));
-    dpotrf = reinterpret_cast<decltype(dpotrf)>(dlsym(solver, "rocsolver_dpotrf"));
-    dpotri = reinterpret_cast<decltype(dpotri)>(dlsym(solver, "rocsolver_dpotri"));
-    if (!create_handle || !destroy_handle || !set_stream || !dgemm || !dpotrf || !dpotri) {
-      *err = "algo=admm: rocBLAS / rocSOLVER entry points missing";
+    dtrsm = reinterpret_cast<decltype(dtrsm)>(dlsym(blas, "rocblas_dtrsm"));
+    dsyrk = reinterpret_cast<decltype(dsyrk)>(dlsym(blas, "rocblas_dsyrk"));
+    if (!create_handle || !destroy_handle || !set_stream || !dgemm || !dtrsm || !dsyrk) {
+      *err = "algo=admm: rocBLAS entry points missing";
       return false;
     }
     return true;
   }
 };
-constexpr int kOpNone = 111;     // rocblas_operation_none
-constexpr int kFillLower = 122;  // rocblas_fill_lower
+constexpr int kOpNone = 111, kOpTrans = 112;  // rocblas_operation_none / _transpose
+constexpr int kFillLower = 122;               // rocblas_fill_lower
+constexpr int kNonUnit = 131;                 // rocblas_diagonal_non_unit
+constexpr int kSideLeft = 141, kSideRight = 142;
+constexpr int kNB = 64;                       // Cholesky block
 
 // ---- kernels ---------------------------------------------------------------------------
 
@@ -115,6 +121,39 @@ __global__ void k_copy_add_diag(int64_t n2, int32_t m, const double* __restrict_
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n2;
        k += (int64_t)gridDim.x * blockDim.x)
     P[k] = T[k] + ((k / m == k % m) ? diag : 0.0);
+}
+
+// Cholesky factor of one kb x kb diagonal block (column-major, lower), in LDS, one workgroup of
+// 64 threads: thread i owns row i.  *info becomes the 1-based global index of a non-positive pivot.
+__global__ __launch_bounds__(kNB) void k_potf2(int32_t kb, int32_t k0, int32_t lda, double* __restrict__ Ablk,
+                                               int32_t* __restrict__ info) {
+  __shared__ double a[kNB][kNB + 1];
+  const int i = threadIdx.x;
+  for (int j = 0; j < kb; ++j) a[i][j] = (i < kb && j <= i) ? Ablk[(int64_t)j * lda + i] : 0.0;
+  __syncthreads();
+  for (int j = 0; j < kb; ++j) {
+    const double d = a[j][j];
+    if (!(d > 0.0)) {
+      if (i == 0) atomicCAS(info, 0, k0 + j + 1);
+      return;
+    }
+    const double piv = sqrt(d);
+    __syncthreads();
+    if (i == j) a[j][j] = piv;
+    if (i > j && i < kb) a[i][j] = a[i][j] / piv;
+    __syncthreads();
+    if (i > j && i < kb)
+      for (int c = j + 1; c <= i; ++c) a[i][c] -= a[i][j] * a[c][j];
+    __syncthreads();
+  }
+  if (i < kb)
+    for (int j = 0; j <= i; ++j) Ablk[(int64_t)j * lda + i] = a[i][j];
+}
+
+__global__ void k_identity(int64_t n2, int32_t m, double* __restrict__ X) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n2;
+       k += (int64_t)gridDim.x * blockDim.x)
+    X[k] = (k / m == k % m) ? 1.0 : 0.0;
 }
 
 // estimate.c:160-163: the lower triangle (row-major) takes the computed upper one
@@ -225,6 +264,13 @@ slim_csr_t* learn_admm(int32_t nrows, const ssize_t* rowptr, const int32_t* rowi
   const int64_t n2 = (int64_t)m * m;
   std::printf("Learning the model using ADMM... \n");  // estimate.c:41
   std::fflush(stdout);
+  const bool trace = std::getenv("SLIM_GPU_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (trace)
+      std::fprintf(stderr, "[trace] admm %-28s %8.1f ms\n", what,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   try {
     (void)hipGetLastError();
     int ndev = 0;
@@ -242,6 +288,7 @@ slim_csr_t* learn_admm(int32_t nrows, const ssize_t* rowptr, const int32_t* rowi
     static std::string load_err;
     std::call_once(once, [&]() { loaded = libs.load(&load_err); });
     if (!loaded) return fail(SLIM_ERROR, "SLIM_Learn: " + load_err);
+    mark("libraries resolved");
     hipDeviceProp_t prop;
     int dev = 0;
     ADMM_TRY(hipGetDevice(&dev));
@@ -255,6 +302,7 @@ slim_csr_t* learn_admm(int32_t nrows, const ssize_t* rowptr, const int32_t* rowi
       return fail(SLIM_ERROR, "SLIM_Learn(admm): rocblas_create_handle failed");
     }
     libs.set_stream(handle, st);
+    mark("rocblas handle");
     struct Cleanup {
       DenseLibs& l;
       void* h;
@@ -291,21 +339,41 @@ slim_csr_t* learn_admm(int32_t nrows, const ssize_t* rowptr, const int32_t* rowi
     hipLaunchKernelGGL(k_copy_add_diag, dim3(grid_for(n2, 256, cap)), dim3(256), 0, st, n2, m, T.p, P.p,
                        opt.l2r + rho);
     ADMM_TRY(hipGetLastError());
-    // row-major 'U' == column-major lower
-    if (libs.dpotrf(handle, kFillLower, m, P.p, m, d_info.p) != 0)
-      return fail(SLIM_ERROR, "SLIM_Learn(admm): rocsolver_dpotrf failed");
+    // Blocked right-looking Cholesky of P in place (column-major lower == the row-major upper
+    // triangle LAPACKE_dpotrf(ROW_MAJOR, 'U') fills, estimate.c:150), then the inverse.
+    const double one = 1.0, zero = 0.0, minus_one = -1.0;
+    ADMM_TRY(hipMemsetAsync(d_info.p, 0, sizeof(int32_t), st));
+    for (int32_t k = 0; k < m; k += kNB) {
+      const int32_t kb = std::min(kNB, m - k), rest = m - k - kb;
+      double* Akk = P.p + (int64_t)k * m + k;
+      hipLaunchKernelGGL(k_potf2, dim3(1), dim3(kNB), 0, st, kb, k, m, Akk, d_info.p);
+      if (rest > 0) {
+        double* A21 = Akk + kb;                    // rows k+kb.., columns k..k+kb
+        double* A22 = Akk + (int64_t)kb * m + kb;  // trailing block
+        if (libs.dtrsm(handle, kSideRight, kFillLower, kOpTrans, kNonUnit, rest, kb, &one, Akk, m, A21, m) != 0 ||
+            libs.dsyrk(handle, kFillLower, kOpNone, rest, kb, &minus_one, A21, m, &one, A22, m) != 0)
+          return fail(SLIM_ERROR, "SLIM_Learn(admm): rocBLAS dtrsm / dsyrk failed");
+      }
+    }
+    ADMM_TRY(hipGetLastError());
     int32_t info = 0;
     ADMM_TRY(hipMemcpyAsync(&info, d_info.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     ADMM_TRY(hipStreamSynchronize(st));
     if (info != 0) return fail(SLIM_ERROR, "SLIM_Learn(admm): R^T R + (l2 + rho) I is not positive definite");
-    if (libs.dpotri(handle, kFillLower, m, P.p, m, d_info.p) != 0)
-      return fail(SLIM_ERROR, "SLIM_Learn(admm): rocsolver_dpotri failed");
-    hipLaunchKernelGGL(k_symmetrize, dim3(grid_for(n2, 256, cap)), dim3(256), 0, st, m, P.p);
+    mark("R^T R + Cholesky");
+    // X = L^-1 (W's storage is free until the iterations start), P^-1 = X^T X
+    hipLaunchKernelGGL(k_identity, dim3(grid_for(n2, 256, cap)), dim3(256), 0, st, n2, m, W.p);
+    if (libs.dtrsm(handle, kSideLeft, kFillLower, kOpNone, kNonUnit, m, m, &one, P.p, m, W.p, m) != 0 ||
+        libs.dgemm(handle, kOpTrans, kOpNone, m, m, m, &one, W.p, m, W.p, m, &zero, P.p, m) != 0)
+      return fail(SLIM_ERROR, "SLIM_Learn(admm): rocBLAS dtrsm / dgemm failed");
+    ADMM_TRY(hipMemsetAsync(W.p, 0, sizeof(double) * (size_t)n2, st));
+    hipLaunchKernelGGL(k_symmetrize, dim3(grid_for(n2, 256, cap)), dim3(256), 0, st, m, P.p);  // :160-163
     ADMM_TRY(hipGetLastError());
     // A = P T (row-major): column-major A^T = T^T P^T -> dgemm(T, P)
-    const double one = 1.0, zero = 0.0;
     if (libs.dgemm(handle, kOpNone, kOpNone, m, m, m, &one, T.p, m, P.p, m, &zero, A.p, m) != 0)
       return fail(SLIM_ERROR, "SLIM_Learn(admm): rocblas_dgemm failed");
+    ADMM_TRY(hipStreamSynchronize(st));
+    mark("inverse + A = P T");
     const double irho = 1.0 / rho, kappa = opt.l1r / rho;
     for (int it = 0; it < maxiters; ++it) {
       hipLaunchKernelGGL(k_w_pre, dim3(grid_for(n2, 256, cap)), dim3(256), 0, st, n2, rho, W.p, C.p);
@@ -324,6 +392,7 @@ slim_csr_t* learn_admm(int32_t nrows, const ssize_t* rowptr, const int32_t* rowi
     std::vector<int64_t> h_cnt((size_t)m + 1, 0);
     ADMM_TRY(hipMemcpyAsync(h_cnt.data(), d_cnt.p, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, st));
     ADMM_TRY(hipStreamSynchronize(st));
+    mark("30 iterations + row counts");
     std::vector<int64_t> h_ptr((size_t)m + 1, 0);
     for (int32_t i = 0; i < m; ++i) h_ptr[(size_t)i + 1] = h_ptr[(size_t)i] + h_cnt[(size_t)i];
     const int64_t wnnz = h_ptr[(size_t)m];
