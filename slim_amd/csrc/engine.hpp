@@ -83,7 +83,7 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
                        int32_t* output, float* scores, int32_t* counts);
 
 // admm.hip: SLIM_Learn(algo = admm), the reference's dense ADMM solver (estimate.c:38-304) with
-// rocSOLVER / rocBLAS for the factorisation and the products and HIP kernels for the rest.
+// rocBLAS for the panel solves, updates and products and HIP kernels for the rest.
 slim_csr_t* learn_admm(int32_t nrows, const ssize_t* rowptr, const int32_t* rowind,
                        const float* rowval, const LearnOptions& opt, int32_t* status);
 
