@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("SLIM_BENCH_CPU_THREADS", "32")),
                     help="threads of the parallel CPU-baseline modes (0 = all physical cores; on "
                          "the 128-core boxes of this pool one round then takes ~3 minutes)")
+    ap.add_argument("--no-whole-matrix", action="store_true",
+                    help="N >= 4: skip the extra whole-matrix (strong-scaling) step")
     ap.add_argument("--replicate", default="broadcast", choices=["broadcast", "generate"])
     ap.add_argument("--backend", default=os.environ.get("SLIM_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several "
@@ -88,9 +90,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the one-rank-per-GPU job ourselves -- the
+        # same command line under torch.distributed.run (what the driver does for N > 1)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SLIM CD path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -200,6 +213,31 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+    # per-rank solver-kernel time of the timed steps (how even the shards were)
+    rank_kernel_ms = [acc["kernel_ms"]]
+    if world > 1:
+        kt = torch.tensor([acc["kernel_ms"]], dtype=torch.float64, device=cdev)
+        all_kt = [torch.zeros_like(kt) for _ in range(world)]
+        dist.all_gather(all_kt, kt)
+        rank_kernel_ms = [float(t.item()) for t in all_kt]
+
+    # N >= 4: north_star's target itself as a secondary figure -- ONE step over the whole
+    # matrix, its columns split over the GPUs (strong scaling), outside the timed region
+    strong_whole = None
+    if world >= 4 and not strong and args.workload != "ml100k" and not args.no_whole_matrix:
+        fence()
+        tw = time.perf_counter()
+        Ww, stw = mat.learn(col_begin=0, col_end=ncols, shard=(rank, world), **opts)
+        if world > 1:
+            Ww = gather_model(Ww, dst=0)
+        fence()
+        tw = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        strong_whole = {"columns": int(ncols), "seconds": float(tw.item()),
+                        "value": ncols / float(tw.item()), "unit": "item-columns/s",
+                        "note": "one untimed-by-contract step: all item columns of the matrix, "
+                                "sharded over the %d GPUs (strong scaling)" % world}
+        del Ww
 
     if rank == 0:
         cols_total = args.steps * span
@@ -218,6 +256,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": args.scaling,
+            "ranks": {"world": world, "backend": ("nccl (RCCL)" if args.backend == "nccl" else args.backend)
+                      if world > 1 else "none (one process)",
+                      "kernel_ms_per_rank": [round(v, 1) for v in rank_kernel_ms]},
             "vs_baseline": None,
             "dtype": "f32",
             "data": "fixture tests/golden/ml100k-train.csr" if args.workload == "ml100k" else "synthetic",
@@ -255,6 +296,8 @@ def main():
                         "(binary: 4G+8D+4U+8nnzW), SURVEY.md 8(d)",
             },
         }
+        if strong_whole is not None:
+            out["strong_whole_matrix"] = strong_whole
         if world == 1:
             out["parity"] = ml100k_parity(dev.index)
         if world == 1 and args.cpu_seconds > 0 and args.workload != "ml100k":

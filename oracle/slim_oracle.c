@@ -749,13 +749,19 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
  * the coordinates outside its own active set.  Per member the algorithm is
  * EstimateModelCD/CoordinateDescent unchanged (reference arithmetic: fp64,
  * 3-pass), so this is the same restatement with a different ShuffleList.     */
-int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
-                             const int32_t *rowind, const float *rowval,
-                             const oracle_cfg_t *cfg, int32_t tileP,
-                             int32_t nwork, const int32_t *order,
-                             int64_t **r_colptr, int32_t **r_colind,
-                             float **r_colval, oracle_colstat_t *stats,
-                             double *r_error, double *r_objval) {
+/* imodel_* : column view of a previous model (warm start, estimate.c:453-464: the
+ * previous coefficients of the coordinates that are active now, folded into yhat by
+ * cd.c:108-110 before the first sweep) or NULL.                                  */
+int32_t oracle_learn_cd_tile_warm(int32_t nrows, const int64_t *rowptr,
+                                  const int32_t *rowind, const float *rowval,
+                                  const oracle_cfg_t *cfg, int32_t tileP,
+                                  int32_t nwork, const int32_t *order,
+                                  const int64_t *imodel_colptr,
+                                  const int32_t *imodel_colind,
+                                  const float *imodel_colval, int32_t imodel_ncols,
+                                  int64_t **r_colptr, int32_t **r_colind,
+                                  float **r_colval, oracle_colstat_t *stats,
+                                  double *r_error, double *r_objval) {
   const int64_t nnz = rowptr[nrows];
   const int32_t ncols = oracle_ncols(nnz, rowind);
   if (ncols <= 0 || tileP <= 0) return -1;
@@ -852,6 +858,16 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
         for (int64_t j = cs; j < ce; j++) y[colind[j]] = colval ? colval[j] : 1.0;
         int64_t cap = 50 * (ce - cs);
         int32_t maxit = cap < cfg->maxniters ? (int32_t)cap : cfg->maxniters;
+        /* estimate.c:453-464 initial solution (in the FSLIM branch the reference never sets
+         * its -0.1 flags, estimate.c:424-431: warm start is a no-op there) */
+        if (imodel_colptr && iC < imodel_ncols && cfg->nnbrs <= 0) {
+          for (int64_t j = imodel_colptr[iC]; j < imodel_colptr[iC + 1]; j++) {
+            const int32_t k = imodel_colind[j];
+            if (k < ncols && am[k]) x[k] = imodel_colval[j];
+          }
+          for (int32_t k = 0; k < nu; k++) /* cd.c:108-110 */
+            if (am[uni[k]]) add_spvec(&A, uni[k], x[uni[k]], yhat);
+        }
         int32_t t, rstatus = 0;
         for (t = 0; t < maxit; t++) {
           double dltx = 0.0;
@@ -944,6 +960,18 @@ int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
   if (r_error) *r_error = error;
   if (r_objval) *r_objval = objval;
   return ncols;
+}
+
+int32_t oracle_learn_cd_tile(int32_t nrows, const int64_t *rowptr,
+                             const int32_t *rowind, const float *rowval,
+                             const oracle_cfg_t *cfg, int32_t tileP,
+                             int32_t nwork, const int32_t *order,
+                             int64_t **r_colptr, int32_t **r_colind,
+                             float **r_colval, oracle_colstat_t *stats,
+                             double *r_error, double *r_objval) {
+  return oracle_learn_cd_tile_warm(nrows, rowptr, rowind, rowval, cfg, tileP, nwork, order,
+                                   NULL, NULL, NULL, 0, r_colptr, r_colind, r_colval, stats,
+                                   r_error, r_objval);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -144,11 +144,21 @@ def tile_work_order(R, col_begin=0, col_end=None):
 
 def learn_cd_tile(R, tileP=32, order=None, l1r=1.0, l2r=1.0, optTol=1e-7, maxniters=10000,
                   nthreads=1, seed=1, binary=False, return_stats=False, tiles=None, nnbrs=0,
-                  simtype=0):
+                  simtype=0, imodel=None):
     """EstimateModelCD in the tile kernel's visiting order (see oracle_learn_cd_tile).
     tiles=(first, count): walk only those tiles of the work list (their position keys the
-    visiting order, so a tile of a larger launch can be checked alone)."""
+    visiting order, so a tile of a larger launch can be checked alone).  imodel: scipy sparse
+    W of a previous solve (warm start, estimate.c:453-464 + cd.c:108-110)."""
     L = lib()
+    ic_ptr = ic_ind = ic_val = None
+    ic_n = 0
+    if imodel is not None:
+        Wc = sp.csc_matrix(imodel)
+        Wc.sort_indices()
+        ic_ptr = np.ascontiguousarray(Wc.indptr, dtype=np.int64)
+        ic_ind = np.ascontiguousarray(Wc.indices, dtype=np.int32)
+        ic_val = np.ascontiguousarray(Wc.data, dtype=np.float32)
+        ic_n = Wc.shape[1]
     nrows, ptr, ind, val = _csr_arrays(R, binary)
     if order is None:
         order = tile_work_order(R)
@@ -159,13 +169,15 @@ def learn_cd_tile(R, tileP=32, order=None, l1r=1.0, l2r=1.0, optTol=1e-7, maxnit
     stats = np.zeros(ncols, dtype=COLSTAT_DTYPE)
     wptr, wind, wval = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_float)()
     err, obj = C.c_double(0), C.c_double(0)
-    L.oracle_learn_cd_tile.restype = C.c_int32
-    n = L.oracle_learn_cd_tile(C.c_int32(nrows), _p(ptr, C.c_int64), _p(ind, C.c_int32),
-                               _p(val, C.c_float), C.byref(cfg), C.c_int32(tileP),
-                               C.c_int32(order.size), _p(order, C.c_int32),
-                               C.byref(wptr), C.byref(wind), C.byref(wval),
-                               stats.ctypes.data_as(C.POINTER(ColStat)),
-                               C.byref(err), C.byref(obj))
+    L.oracle_learn_cd_tile_warm.restype = C.c_int32
+    n = L.oracle_learn_cd_tile_warm(C.c_int32(nrows), _p(ptr, C.c_int64), _p(ind, C.c_int32),
+                                    _p(val, C.c_float), C.byref(cfg), C.c_int32(tileP),
+                                    C.c_int32(order.size), _p(order, C.c_int32),
+                                    _p(ic_ptr, C.c_int64), _p(ic_ind, C.c_int32),
+                                    _p(ic_val, C.c_float), C.c_int32(ic_n),
+                                    C.byref(wptr), C.byref(wind), C.byref(wval),
+                                    stats.ctypes.data_as(C.POINTER(ColStat)),
+                                    C.byref(err), C.byref(obj))
     if n < 0:
         raise RuntimeError("oracle_learn_cd_tile failed")
     indptr = np.ctypeslib.as_array(wptr, shape=(n + 1,)).copy()

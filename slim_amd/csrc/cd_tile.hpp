@@ -74,6 +74,39 @@ __device__ __forceinline__ bool tile_active(float xv) { return xv > -3.0e38f; }
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(int& v) { asm volatile("" : "+v"(v)); }
 
+// Broadcast inside each row of 16 lanes: every lane reads lane N of its own row (DPP
+// row_newbcast, one VALU move, no LDS round trip and no address register).  The visit
+// distributes the user ids / values of a 64-nnz block with it: the block is loaded so that the
+// 16-lane rows of a lane group (P lanes = the P problems of one user) hold the same 16 entries,
+// P / 16 registers per block, and step j of group g reads entry g * P + j.
+template <int N>
+__device__ __forceinline__ int row_bcast_c(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int row_bcast(int v, int n) {  // n: a constant after unrolling
+  switch (n & 15) {
+    case 0: return row_bcast_c<0>(v);
+    case 1: return row_bcast_c<1>(v);
+    case 2: return row_bcast_c<2>(v);
+    case 3: return row_bcast_c<3>(v);
+    case 4: return row_bcast_c<4>(v);
+    case 5: return row_bcast_c<5>(v);
+    case 6: return row_bcast_c<6>(v);
+    case 7: return row_bcast_c<7>(v);
+    case 8: return row_bcast_c<8>(v);
+    case 9: return row_bcast_c<9>(v);
+    case 10: return row_bcast_c<10>(v);
+    case 11: return row_bcast_c<11>(v);
+    case 12: return row_bcast_c<12>(v);
+    case 13: return row_bcast_c<13>(v);
+    case 14: return row_bcast_c<14>(v);
+    default: return row_bcast_c<15>(v);
+  }
+}
+__device__ __forceinline__ float row_bcast(float v, int n) {
+  return __int_as_float(row_bcast(__float_as_int(v), n));
+}
+
 typedef unsigned long long tile_gran_t;
 
 __device__ __forceinline__ void gran_store(tile_gran_t* p, uint32_t epoch, float v) {
@@ -89,7 +122,22 @@ __device__ __forceinline__ tile_gran_t gran_load(const tile_gran_t* p) {
 // phase is a template parameter so that the cluster geometry stays a function of kernel
 // arguments (re-derivable, no live registers across the visit loop).  Returns false when
 // the launch was aborted.
-template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM, bool HI>
+//
+// FOLD selects how warm-start coefficients enter the residual (cd.c:108-110), 0: not at all (a
+// kernel for cold starts only), 1: column by column (one pass over every column of the union
+// list: gather + write-back of its users' lines), 2: row by row -- r[u] = y[u] - sum over the
+// items j of row u of v_uj x[j], the x lines gathered from ONE copy per cluster (member 0's),
+// which the XCD's L2 can hold, and every residual line written exactly once.
+//
+// bid = the workgroup's position in the launch.  With S.xcd_swizzle the hardware's round-robin
+// placement (block b on XCD b % 8, observed) is undone so that consecutive positions -- the
+// members of a cluster -- share an XCD and its L2; nothing depends on it for correctness.
+__device__ __forceinline__ int tile_block_id(const SolveArgs& S) {
+  const int b = (int)blockIdx.x, g = (int)gridDim.x;
+  return S.xcd_swizzle ? (b & 7) * (g >> 3) + (b >> 3) : b;
+}
+
+template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM, bool HI, int FOLD>
 __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& S, uint32_t& epoch) {
   constexpr int NT = 64 * NW;  // threads per workgroup
   constexpr int SL = 64 / P;       // users per wavefront step (lane groups)
@@ -116,18 +164,19 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
   // cluster geometry: K consecutive workgroups share tiles, member mk owns users
   // [ubase, uend)
   const int K = HI ? S.cluster_hi : S.cluster;
-  const int cid = (int)blockIdx.x / K, mk = (int)blockIdx.x % K;
+  const int bid = tile_block_id(S);
+  const int cid = bid / K, mk = bid % K;
   const int32_t* __restrict__ ubounds = HI ? S.ubounds_hi : S.ubounds;
   const int ubase = ubounds[mk], uend = ubounds[mk + 1];
   tile_gran_t* const mbox = (HI ? S.mailbox_hi : S.mailbox) + (int64_t)cid * (2 * kTileKMax * P + 8);
   // this member's partial aTy of the tile's columns over ITS users, [ncols][P] (screen pass)
-  float* const part = S.atypart + (int64_t)blockIdx.x * S.x_stride;
+  float* const part = S.atypart + (int64_t)bid * S.x_stride;
   const int64_t* __restrict__ csplit = HI ? S.csplit_hi : S.csplit;  // [ncols][K+1] slice boundaries
   const int grp_end = HI ? S.nheavy : S.ngroups;
   if (tid == 0) s_abort = 0;
-  float* __restrict__ r = S.slab + (int64_t)blockIdx.x * S.slab_stride;   // [my users][P]
-  float* x = S.xslab + (int64_t)blockIdx.x * S.x_stride;                 // [ncols][P]
-  int* __restrict__ ul = S.ulist + (int64_t)blockIdx.x * S.u_stride;      // union list
+  float* __restrict__ r = S.slab + (int64_t)bid * S.slab_stride;   // [my users][P]
+  float* x = S.xslab + (int64_t)bid * S.x_stride;                 // [ncols][P]
+  int* __restrict__ ul = S.ulist + (int64_t)bid * S.u_stride;      // union list
   const int64_t* __restrict__ colptr = A.colptr;
   const int32_t* __restrict__ ci = A.colind;
   const float* __restrict__ cv = A.colval;
@@ -425,7 +474,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 
     // -- warm start (estimate.c:453-464): previous coefficients of active coordinates
     // (in the FSLIM branch the reference never sets its warm-start flags: a no-op there)
-    const bool warm = S.icolptr != nullptr && !FSLIM;
+    const bool warm = FOLD != 0 && S.icolptr != nullptr && !FSLIM;
     if (warm) {
 #pragma unroll
       for (int pp = 0; pp < PPW; ++pp) {
@@ -498,8 +547,15 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     // HI (latency-bound: slices of a few hundred nnz): the ids of the next visit's first
     // block are requested while this visit waits for the cluster, [sn_v, sn_v + nn_v) = that
     // slice
-    int pf_id = 0;
-    float pf_v = 0.0f;
+    constexpr int NR = P / 16;  // id / value registers per 64-nnz block (see row_bcast)
+    const int ent0 = slot * P + (lane & 15);  // block entry this lane loads into register 0
+    int pf_id[NR];
+    float pf_v[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      pf_id[k] = 0;
+      pf_v[k] = 0.0f;
+    }
     int64_t pf_at = -1;  // slice start the prefetched block belongs to (-1: none)
     auto visit = [&](const int i, const int64_t s, const int64_t e, const int64_t len,
                      const float xi, const float cn, const float sq, const bool live, float& dlt,
@@ -509,23 +565,33 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       const bool part = live && tile_active(xi);
       if (!__any(part)) return;
       constexpr int64_t CH = 64 * NW;  // nnz per workgroup chunk
-      int idreg = 0;
-      float vreg = 0.0f;
+      int idreg[NR];
+      float vreg[NR];
       float r_c[STEPS];
       int nhere = 0;  // valid nnz of this wavefront's 64-block in the current chunk
-      // this wavefront's 64 consecutive nnz of chunk c0: one coalesced request per array
+      int nloc = 0;   // ... of this lane group's P entries of it
+      // this wavefront's 64 consecutive nnz of chunk c0: one coalesced request per array and
+      // register (the rows of a lane group load the same 16 entries)
       auto load_ids = [&](const int64_t c0) {
         const int64_t b0 = c0 + 64 * wave;
         const int64_t left = e - b0;
         nhere = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
-        const bool ok = lane < nhere;
+        nloc = nhere - slot * P;
         if (HI && c0 == pf_here) {  // requested during the previous visit
-          idreg = pf_id;
-          vreg = pf_v;
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            idreg[k] = pf_id[k];
+            vreg[k] = pf_v[k];
+          }
           pf_here = -1;  // (pf_id is reused for the next visit before this block is re-read)
         } else {
-          idreg = ok ? ci[b0 + lane] - ubase : 0;
-          vreg = ok ? (HAS_VAL ? cv[b0 + lane] : 1.0f) : 0.0f;
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            const int ent = ent0 + 16 * k;
+            const bool ok = ent < nhere;
+            idreg[k] = ok ? ci[b0 + ent] - ubase : 0;
+            vreg[k] = ok ? (HAS_VAL ? cv[b0 + ent] : 1.0f) : 0.0f;
+          }
         }
       };
       // gather the residual lines of the block: STEPS loads per lane in flight
@@ -533,10 +599,9 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         if (nhere > 0) {
 #pragma unroll
           for (int j = 0; j < STEPS; ++j) {
-            const int src = j * SL + slot;
-            const int u = __shfl(idreg, src);
+            const int u = row_bcast(idreg[j >> 4], j & 15);
             r_c[j] = 0.0f;
-            if (src < nhere)
+            if (j < nloc)
               r_c[j] = *reinterpret_cast<const float*>(rb + (((uint32_t)u * (uint32_t)(4 * P)) | qoff));
           }
 #pragma unroll
@@ -547,7 +612,8 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         float a = 0.0f;
         if (nhere > 0) {
 #pragma unroll
-          for (int j = 0; j < STEPS; ++j) a += __shfl(vreg, j * SL + slot) * r_c[j];
+          for (int j = 0; j < STEPS; ++j)  // (entries past the slice were gathered as 0)
+            a += HAS_VAL ? row_bcast(vreg[j >> 4], j & 15) * r_c[j] : r_c[j];
         }
         return a;
       };
@@ -556,15 +622,29 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         if (nhere > 0) {
 #pragma unroll
           for (int j = 0; j < STEPS; ++j) {
-            const int src = j * SL + slot;
-            const int u = __shfl(idreg, src);
-            const float v = __shfl(vreg, src);
-            if (src < nhere)
+            const int u = row_bcast(idreg[j >> 4], j & 15);
+            const float v = HAS_VAL ? row_bcast(vreg[j >> 4], j & 15) : 1.0f;
+            if (j < nloc)
               *reinterpret_cast<float*>(rbw + (((uint32_t)u * (uint32_t)(4 * P)) | qoff)) =
                   r_c[j] - d * v;
           }
         }
       };
+
+      if (FOLD == 1 && mode == 1) {
+        // fold of a warm-start coefficient: r -= x_i a_i, one pass per chunk (ids, gather,
+        // write-back); no dot, no exchange.  Two folds can touch the same user line: the
+        // closing barrier stays.
+        const float d = (part && (xi > kEps || xi < -kEps)) ? xi : 0.0f;
+        if (!__any(d != 0.0f)) return;
+        for (int64_t c = s; c < e; c += CH) {
+          load_ids(c);
+          gather();
+          scatter(d);
+        }
+        __syncthreads();
+        return;
+      }
 
       const uint64_t p0 = tick();
       float acc = 0.0f;
@@ -572,7 +652,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       for (; c0 + CH < e; c0 += CH) {
         load_ids(c0);
         gather();
-        if (mode == 0) acc += dot_block();
+        acc += dot_block();
       }
       load_ids(c0);  // last chunk: kept in registers for the update
       gather();
@@ -582,20 +662,23 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       // flight behind the gather on every path and the dot below waits for the gather only
       // (s_waitcnt vmcnt(1|2)); a load under a condition makes the count path-dependent and the
       // compiler drains the queue instead.
-      if (HI && mode == 0) {
+      if (HI) {
         const int64_t sn = uni(sn_v);
         const int nn = uni(nn_v);
-        int64_t jj = sn + 64 * wave + lane;
-        jj = jj < S.nnz_last ? jj : S.nnz_last;
-        pf_id = ci[jj] - ubase;
-        pf_v = HAS_VAL ? cv[jj] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          int64_t jj = sn + 64 * wave + ent0 + 16 * k;
+          jj = jj < S.nnz_last ? jj : S.nnz_last;
+          pf_id[k] = ci[jj] - ubase;
+          pf_v[k] = HAS_VAL ? cv[jj] : 1.0f;
+        }
         pf_at = (nn > 0 && S.hi_prefetch) ? sn : -1;
       }
       const uint64_t p1 = tick();
 
       float d = 0.0f, nx = xi;
       uint64_t p2 = p1;
-      if (mode == 0) {
+      {
         acc += dot_block();
         if (SL == 4) acc += __shfl_xor(acc, 16);
         acc += __shfl_xor(acc, 32);
@@ -620,11 +703,9 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           dlt += (nx - xi) * (nx - xi);
           if (d != 0.0f) U_q += len;
         }
-      } else {
-        d = (part && (xi > kEps || xi < -kEps)) ? xi : 0.0f;
       }
       const bool upd = __any(d != 0.0f);
-      const bool xch = mode == 0 && __any(part && nx != xi);
+      const bool xch = __any(part && nx != xi);
       const uint64_t p3 = tick();
       if (upd) {
         scatter(d);
@@ -650,7 +731,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     };
 
     const uint64_t t_setup = wall_clock64();
-    if (warm) {
+    if (FOLD == 1 && warm) {
       float unused = 0.0f;
       for (int p = 0; p < nunion; ++p) {
         const int i = uni(ul[p]);
@@ -659,6 +740,102 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
               0.0f, 0.0f, !done_q, unused, 1, 0, 0);
       }
     }
+    if (FOLD == 2 && warm) {
+      // Row-wise fold: r[u][q] = y[u][q] - sum_{j in row u} v_uj x_j[q] over this member's users.
+      // Every member wrote the same warm-start values into its own x; all of them gather from
+      // member 0's copy, so that a cluster keeps ONE [ncols][P] array hot (C5: 2.5 MB; the K
+      // private copies of a cluster would be 20 MB).  One user per wavefront at a time, the 64
+      // ids of a block of its row spread over the lanes, every lane group gathering the lines
+      // of its share (STEPS loads in flight per lane), the ids of the next block -- of this row
+      // or of the wavefront's next user -- requested before the gathers of the current one.
+      // The residual line of a user is read (it holds y) and written once.
+      cluster_barrier();  // member 0's x is complete and visible
+      {
+        const float* __restrict__ xs = S.xslab + (int64_t)(bid - mk) * S.x_stride;
+        const int64_t* __restrict__ rp = A.rowptr + ubase;
+        const int32_t* __restrict__ ri = A.rowind;
+        const float* __restrict__ rv = A.rowval;
+        const int nu = uend - ubase;
+        int u = wave;
+        if (u < nu) {
+          int64_t b = uni(rp[u]), re = uni(rp[u + 1]);
+          int64_t rs_n = 0, re_n = 0;  // row of the wavefront's next user
+          if (u + NW < nu) {
+            rs_n = rp[u + NW];
+            re_n = rp[u + NW + 1];
+          }
+          int id_n[NR];
+          float v_n[NR];
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            int64_t jj = b + ent0 + 16 * k;
+            jj = jj < S.nnz_last ? jj : S.nnz_last;
+            id_n[k] = ri[jj];
+            v_n[k] = HAS_VAL ? rv[jj] : 1.0f;
+          }
+          float acc = 0.0f;
+          float yv = r[(int64_t)u * P + q];
+          for (;;) {
+            const int64_t left = re - b;
+            const int nh = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+            const int nl = nh - slot * P;  // valid entries of this lane group
+            int id[NR];
+            float v[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+              id[k] = id_n[k];
+              v[k] = v_n[k];
+            }
+            // what comes after this block
+            const bool row_end = left <= 64;
+            const int un = u + NW;
+            int64_t nb = b + 64;
+            if (row_end) nb = uni(rs_n);
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+              int64_t jj = nb + ent0 + 16 * k;
+              jj = jj < S.nnz_last ? jj : S.nnz_last;
+              jj = jj < 0 ? 0 : jj;
+              id_n[k] = ri[jj];
+              v_n[k] = HAS_VAL ? rv[jj] : 1.0f;
+            }
+            float xg[STEPS];
+#pragma unroll
+            for (int j = 0; j < STEPS; ++j) {
+              const int jj = row_bcast(id[j >> 4], j & 15);
+              xg[j] = 0.0f;
+              if (j < nl) xg[j] = xs[(int64_t)jj * P + q];
+            }
+#pragma unroll
+            for (int j = 0; j < STEPS; ++j) {
+              const float xv = xg[j];
+              // the coefficients that enter the residual (cd.c:27), inactive = -inf = none
+              const float xe = (xv > kEps || (xv < -kEps && tile_active(xv))) ? xv : 0.0f;
+              acc += (HAS_VAL ? row_bcast(v[j >> 4], j & 15) : 1.0f) * xe;
+            }
+            if (row_end) {
+              if (SL == 4) acc += __shfl_xor(acc, 16);
+              acc += __shfl_xor(acc, 32);
+              if (slot == 0) r[(int64_t)u * P + q] = yv - acc;
+              acc = 0.0f;
+              u = un;
+              if (u >= nu) break;
+              b = nb;
+              re = uni(re_n);
+              yv = r[(int64_t)u * P + q];
+              if (u + NW < nu) {
+                rs_n = rp[u + NW];
+                re_n = rp[u + NW + 1];
+              }
+            } else {
+              b = nb;
+            }
+          }
+        }
+      }
+      cluster_barrier();  // nobody reads member 0's x any more: the sweeps may change it
+    }
+    const uint64_t t_fold = wall_clock64();
 
     // -- sweeps (cd.c:112-139)
     for (int t = 0;; ++t) {
@@ -792,9 +969,10 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       tr[1] = t_setup;
       tr[2] = t_sweeps;
       tr[3] = wall_clock64();
-      tr[4] = blockIdx.x;
+      tr[4] = (uint64_t)bid;
       tr[5] = (uint64_t)nunion;
       tr[6] = (uint64_t)K;
+      tr[7] = t_fold;
       if (PROFILE) {
         uint64_t* pr = S.trace + (int64_t)S.ngroups * 8 + (int64_t)grp * 8;
         for (int k = 0; k < 7; ++k) pr[k] = prof[k];
@@ -817,16 +995,16 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 // profiles/r02/ab_variants.txt, rejected parking a chunk of a visit in LDS, pipelining the id
 // loads of a visit's chunks, an 8-wavefront / 256-VGPR form of the workgroup and a row-wise
 // warm-start fold.)
-template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM = false>
+template <int P, bool HAS_VAL, bool PROFILE, int NW, bool FSLIM = false, int FOLD = 1>
 __global__ __launch_bounds__(64 * NW, 4) void cd_tile_kernel(const DevMatrix A, const SolveArgs S) {
   uint32_t epoch = 0;
   // heavy phase first: whole clusters of S.cluster_hi only (S.cluster divides S.cluster_hi,
   // so the workgroups of a big cluster regroup into whole small ones afterwards)
-  if (S.nheavy > 0 && (int)blockIdx.x < ((int)gridDim.x / S.cluster_hi) * S.cluster_hi) {
-    if (!tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, true>(A, S, epoch)) return;
+  if (S.nheavy > 0 && tile_block_id(S) < ((int)gridDim.x / S.cluster_hi) * S.cluster_hi) {
+    if (!tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, true, FOLD>(A, S, epoch)) return;
     __syncthreads();
   }
-  tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, false>(A, S, epoch);
+  tile_phase<P, HAS_VAL, PROFILE, NW, FSLIM, false, FOLD>(A, S, epoch);
 }
 
 }  // namespace slimamd

@@ -100,6 +100,9 @@ struct SolveArgs {
   // shard_count, ... of a larger cost-ordered list; the visiting permutation is keyed by the
   // tile's position in THAT list, so a column's result does not depend on the shard count
   int32_t shard_count, shard_index;
+  // tile kernel: 1 = undo the round-robin block -> XCD placement so that the members of a
+  // cluster share an XCD (requires gridDim.x % 8 == 0); see tile_block_id()
+  int32_t xcd_swizzle;
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;
   int64_t* out_off;

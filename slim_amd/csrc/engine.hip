@@ -642,6 +642,12 @@ KernelFn pick_kernel(bool lds, bool has_val) {
 
 int round_up(int v, int q) { return (v + q - 1) / q * q; }
 
+// test-only behaviour switches: honoured only when SLIM_GPU_TEST_HOOKS=1 is set as well
+bool test_hook(const char* name) {
+  const char* master = std::getenv("SLIM_GPU_TEST_HOOKS");
+  return master && std::atoi(master) == 1 && std::getenv(name) != nullptr;
+}
+
 constexpr int kBitmapBytes = 64 * 1024;  // dynamic LDS of a tile workgroup (user bitmap): two
                                          // 8-wave workgroups per CU still fit (2 x (64 + 10) KB)
 
@@ -752,11 +758,21 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int tileNW = (nwork + tileP - 1) / tileP >= 2 * m->num_cus ? 8 : 16;
     // (four 4-wavefront workgroups per CU were measured too: no gain, even on columns of ~900 nnz)
     if (const char* e = std::getenv("SLIM_GPU_TILE_NW")) tileNW = std::atoi(e) == 16 ? 16 : 8;
+    // warm start (estimate.c:453-464) on the tile path: how the previous coefficients are folded
+    // into the residual -- "row" (default for 32-wide tiles: one pass over the member's rows,
+    // x lines from one copy per cluster) or "col" (one pass per column of the union list)
+    const bool has_imodel = imodel && imodel->colptr && imodel->ncols > 0;
+    bool row_fold = true;
+    if (const char* e = std::getenv("SLIM_GPU_FOLD")) row_fold = std::strcmp(e, "col") != 0;
     if (use_tile) {
       const bool prof = trace_level >= 2;
       const bool val = !m->binary;
       if (tileP == 32 && opt.nnbrs > 0)
         fn = tile_kernel_p32_fslim(val, tileNW == 16);
+      else if (tileP == 32 && !prof && !has_imodel)
+        fn = tile_kernel_p32_cold(val, tileNW == 16);
+      else if (tileP == 32 && !prof && row_fold)
+        fn = tile_kernel_p32_rowfold(val, tileNW == 16);
       else if (tileP == 32)
         fn = tileNW == 16 ? tile_kernel_p32_nw16(val, prof) : tile_kernel_p32_nw8(val, prof);
       else
@@ -893,6 +909,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     unsigned long long* d_mailbox = nullptr;
     float* d_part = nullptr;
     int bm_shift = 0, bm_words = 1;
+    // dynamic LDS of a tile workgroup: the user bitmap of the screen pass (FSLIM: the select
+    // histograms)
+    size_t tile_lds = 0;
     const size_t mailbox_stride = 2 * (size_t)kTileKMax * (size_t)tileP + 8;
     size_t mailbox_words = 0;
     auto alloc_tiles = [&]() {
@@ -910,13 +929,12 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       while (words_at(bm_shift) * 4 > kBitmapBytes) ++bm_shift;
       bm_words = (int)words_at(bm_shift);
       if (opt.nnbrs > 0) bm_words = std::max(bm_words, tileP * 256);  // FSLIM's select histograms
+      // (the bitmap follows the member's user range, which grows when the fallback below
+      // re-plans without clusters: the launch size must follow it)
+      tile_lds = sizeof(uint32_t) * (size_t)bm_words;
     };
-    // dynamic LDS of a tile workgroup: the user bitmap of the screen pass (FSLIM: the select
-    // histograms)
-    size_t tile_lds = 0;
     if (use_tile) {
       alloc_tiles();
-      tile_lds = sizeof(uint32_t) * (size_t)bm_words;
     } else if (!use_lds) {
       d_slab = ws_get<float>(m->ws_slab, vec_floats * (size_t)nwaves);
     }
@@ -933,7 +951,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     const int32_t* d_icolind = nullptr;
     const float* d_icolval = nullptr;
     int32_t incols = 0;
-    if (imodel && imodel->colptr && imodel->ncols > 0) {
+    if (has_imodel) {
       incols = imodel->ncols;
       const int64_t innz = imodel->colptr[incols];
       int64_t* p = ws_get<int64_t>(m->ws_icolptr, (size_t)incols + 1);
@@ -1045,6 +1063,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.shard_count = opt.shard_count;
       S.shard_index = opt.shard_index;
       S.nnz_last = m->nnz > 0 ? m->nnz - 1 : 0;
+      S.xcd_swizzle = 0;
       if (const char* e = std::getenv("SLIM_GPU_HI_PREFETCH")) S.hi_prefetch = std::atoi(e);
       if (use_tile)
         HIP_TRY(hipMemsetAsync(d_mailbox, 0, sizeof(unsigned long long) * mailbox_words, stream));
@@ -1079,9 +1098,17 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       // test hook: launch the last cluster one member short, which is what a CU mask or a
       // second tenant does to a cluster -- exercises the timeout + fallback path below
       int launch_now = launch_waves;
-      if (use_tile && clusterK > 1 && !cluster_fallback && std::getenv("SLIM_GPU_TEST_DROP_MEMBER")) {
+      // (acts only together with the master switch SLIM_GPU_TEST_HOOKS=1: an inherited
+      // environment must not void production launches)
+      if (use_tile && clusterK > 1 && !cluster_fallback && test_hook("SLIM_GPU_TEST_DROP_MEMBER")) {
         launch_now -= 1;
         S.nheavy = 0;
+      }
+      // members of a cluster on one XCD (one L2): matters for the row-wise fold, whose x lines
+      // are shared by the cluster; placement only, never correctness
+      if (use_tile && clusterK > 1 && launch_now % 8 == 0) {
+        S.xcd_swizzle = 1;
+        if (const char* e = std::getenv("SLIM_GPU_XCD")) S.xcd_swizzle = std::atoi(e) != 0;
       }
       HIP_TRY(hipEventRecord(ev0, stream));
       hipLaunchKernelGGL(fn, dim3(launch_now), dim3(use_tile ? 64 * tileNW : 64),
@@ -1103,7 +1130,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         std::vector<uint64_t> tr(16 * (size_t)S.ngroups);
         HIP_TRY(hipMemcpy(tr.data(), S.trace, sizeof(uint64_t) * tr.size(), hipMemcpyDeviceToHost));
         uint64_t t0 = ~0ull, t1 = 0;
-        double busy = 0, setup = 0, sweeps = 0;
+        double busy = 0, setup = 0, sweeps = 0, fold = 0;
         std::vector<double> dur;
         for (int gI = 0; gI < S.ngroups; ++gI) {
           const uint64_t* e = &tr[8 * (size_t)gI];
@@ -1113,16 +1140,18 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
           busy += double(e[3] - e[0]) * wk;
           setup += double(e[1] - e[0]) * wk;
           sweeps += double(e[2] - e[1]) * wk;
+          fold += double(e[7] - e[1]) * wk;  // warm-start fold (part of "sweeps")
           dur.push_back(double(e[3] - e[0]) * 1e-5);
         }
         std::sort(dur.begin(), dur.end());
         const double span = double(t1 - t0);
         std::fprintf(stderr,
                      "[trace] tiles %d (%d heavy, clusters of %d) on %d workgroups (clusters of %d): span %.2f ms (event %.2f ms), busy/"
-                     "(span*wgs) %.2f, setup %.1f%% sweeps %.1f%% of busy; tile ms min %.2f med "
+                     "(span*wgs) %.2f, setup %.1f%% sweeps %.1f%% (fold %.1f%%) of busy; tile ms min %.2f med "
                      "%.2f p90 %.2f max %.2f\n",
                      S.ngroups, S.nheavy, S.nheavy > 0 ? clusterHi : 0, launch_waves, clusterK, span * 1e-5, ms,
                      busy * clusterK / (span * launch_waves), 100 * setup / busy, 100 * sweeps / busy,
+                     100 * fold / busy,
                      dur.front(), dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back());
         if (S.ngroups >= 16) {  // queue order = cost order: (estimated cost, measured ms)
           std::fprintf(stderr, "[trace] tile cost -> ms, queue order:");

@@ -2,6 +2,7 @@
 // they compile side by side (`make -j`); engine.hip picks one through tile_kernel().
 //   base : <P, HAS_VAL, PROFILE, NW>                       P in {32, 16}, NW in {16, 8}
 //   FSLIM: <32, HAS_VAL, false, NW, true>
+//   cold / row fold: <32, HAS_VAL, false, NW, false, 0 / 2>
 #pragma once
 #include "cd_tile.hpp"
 
@@ -15,6 +16,10 @@ KernelFn tile_kernel_p16_nw16(bool has_val, bool profile);
 KernelFn tile_kernel_p16_nw8(bool has_val, bool profile);
 // P = 32 only: neighbour selection instead of the l1 screen (FSLIM)
 KernelFn tile_kernel_p32_fslim(bool has_val, bool nw16);
+// P = 32 only: a kernel without any warm-start code (cold starts), and one that folds the
+// warm-start coefficients row by row (FOLD = 2); the base instantiations fold column by column
+KernelFn tile_kernel_p32_cold(bool has_val, bool nw16);
+KernelFn tile_kernel_p32_rowfold(bool has_val, bool nw16);
 
 #define SLIM_TILE_INSTANTIATE(NAME, PP, NWW)                                        \
   KernelFn NAME(bool has_val, bool profile) {                                        \

@@ -110,3 +110,48 @@ def test_c5_full_size_tile_matches_oracle_in_tile_order():
     _check_tile_tight(mat, R, tiles[len(tiles) // 2], threads)
     O.cache_setup(False)
     mat.close()
+
+
+@pytest.mark.timeout(1200, method="thread")
+def test_c5_full_size_warm_started_grid_steps_match_oracle():
+    """What config 5 is about (VERDICT r2 missing #2): consecutive (l1, l2) pairs of
+    test/l12file, each solved from the previous model (slim_mselect.c:99-113,
+    estimate.c:453-471, cd.c:108-110), on one whole tile of the 10M x 20K matrix -- slices six
+    chunks long, clusters of 16.  Pair 1 cold, pair 2 (an l2 step: one sweep) and an l1 step
+    (the active sets shrink, several sweeps) warm-started, GPU and oracle each from their own
+    previous model, in the tile's visiting order: <= 2e-5, identical active sets and sweep
+    counts.  Both forms of the fold (row-wise: the default; column-wise) are checked."""
+    import os
+    mat, R = _stage("c5")
+    threads = min(32, O.max_threads())
+    tiles = _batch_tiles(mat, 0, 4096)
+    tile = tiles[len(tiles) // 2]
+    pairs = [tuple(map(float, ln.split())) for ln in
+             open(os.path.join(os.path.dirname(__file__), "golden", "l12file")) if ln.strip()]
+    assert pairs[0] == (0.1, 0.1) and pairs[1] == (0.1, 0.5) and pairs[9] == (0.5, 0.1)
+    O.cache_setup(True)
+    prev_g = prev_o = None
+    for step, (l1, l2) in enumerate((pairs[0], pairs[1], pairs[9])):
+        kw = dict(l1r=l1, l2r=l2, optTol=1e-7)
+        W, st = mat.learn(columns=tile, niters=10000, seed=1, imodel=prev_g, **kw)
+        cs = mat.column_stats()
+        sweeps_g, na_g = cs.sweeps[tile].copy(), cs.nacols[tile].copy()
+        Wo, so, _, _ = O.learn_cd_tile(R, tileP=32, order=tile, maxniters=10000, seed=1,
+                                       nthreads=threads, binary=True, return_stats=True,
+                                       imodel=prev_o, **kw)
+        assert W[:, tile].nnz > 0
+        assert np.array_equal(na_g, so["nacols"][tile])
+        assert (sweeps_g == so["sweeps"][tile]).mean() >= 0.98
+        assert maxdiff(W[:, tile], Wo[:, tile]) <= 2e-5
+        if step == 1:
+            assert sweeps_g.max() <= 2          # an l2 step of 0.4 moves nothing: one sweep
+            os.environ["SLIM_GPU_FOLD"] = "col"  # the other fold: the same step again
+            try:
+                Wc, _ = mat.learn(columns=tile, niters=10000, seed=1, imodel=prev_g, **kw)
+            finally:
+                del os.environ["SLIM_GPU_FOLD"]
+            assert np.array_equal(mat.column_stats().sweeps[tile], sweeps_g)
+            assert maxdiff(Wc[:, tile], Wo[:, tile]) <= 2e-5
+        prev_g, prev_o = W, Wo
+    O.cache_setup(False)
+    mat.close()

@@ -371,6 +371,38 @@ def test_tile_kernel_heavy_phase_long_slices():
     m.close()
 
 
+@pytest.mark.parametrize("fold", ["row", "col"])
+def test_tile_kernel_warm_start_matches_oracle_tile_walk(fold, monkeypatch):
+    """Warm start on the tile path, visit for visit: the previous model folded into the residual
+    row by row (default) or column by column, then the sweeps in the tile's order -- against
+    oracle_learn_cd_tile(..., imodel) (estimate.c:453-464, cd.c:108-110) from the same previous
+    model.  Slices longer than a workgroup chunk, valued and binary matrices, no clusters /
+    clusters of 4 / a heavy phase."""
+    monkeypatch.setenv("SLIM_GPU_FOLD", fold)
+    for binary in (False, True):
+        R = _random_ratings(60000, 96, 0.08, 11)   # ~4800 nnz per column
+        if binary:
+            R.data[:] = 1.0
+        m = DeviceMatrix.from_scipy(R, binary=binary)
+        first_o = O.learn_cd_tile(R, tileP=32, seed=3, nthreads=8, l1r=3.0, l2r=1.0, binary=binary)
+        Wo, so, _, obj_o = O.learn_cd_tile(R, tileP=32, seed=3, nthreads=8, l1r=1.0, l2r=0.5,
+                                           imodel=first_o, return_stats=True, binary=binary)
+        cold_sweeps = O.learn_cd_tile(R, tileP=32, seed=3, nthreads=8, l1r=1.0, l2r=0.5,
+                                      return_stats=True, binary=binary)[1]["sweeps"].sum()
+        assert so["sweeps"].sum() < cold_sweeps
+        for geom in (dict(cluster=1, heavy_tiles=0), dict(cluster=4, heavy_tiles=0),
+                     dict(cluster=2, heavy_tiles=1, heavy_cluster=4)):
+            first, _ = m.learn(seed=3, kernel=KERNEL_TILE, l1r=3.0, l2r=1.0, **geom)
+            assert maxdiff(first, first_o) <= 5e-5
+            W, st = m.learn(seed=3, kernel=KERNEL_TILE, l1r=1.0, l2r=0.5, imodel=first, **geom)
+            cs = m.column_stats()
+            assert maxdiff(W, Wo) <= 5e-5
+            assert np.array_equal(cs.nacols, so["nacols"])
+            assert (cs.sweeps == so["sweeps"]).mean() >= 0.98
+            assert abs(st["objval"] - obj_o) <= 1e-4 * obj_o
+        m.close()
+
+
 def test_tile_kernel_ratings_and_warm_start():
     R = _random_ratings(40000, 150, 0.01, 3)   # 4*(40000+300) > 64 KiB: no LDS kernel
     m = DeviceMatrix.from_scipy(R)

@@ -135,10 +135,42 @@ def test_cluster_timeout_falls_back_to_unclustered_solve(ml100k, monkeypatch, ca
     R, _ = ml100k
     m = DeviceMatrix.from_scipy(R)
     want, _ = m.learn(seed=1, kernel=KERNEL_TILE, cluster=1)
+    monkeypatch.setenv("SLIM_GPU_TEST_HOOKS", "1")
     monkeypatch.setenv("SLIM_GPU_TEST_DROP_MEMBER", "1")
     got, st = m.learn(seed=1, kernel=KERNEL_TILE, cluster=4)
     assert "re-solving" in capfd.readouterr().err
     assert got.nnz == want.nnz and maxdiff(got, want) == 0.0
+    m.close()
+
+
+@pytest.mark.timeout(180, method="thread")
+def test_cluster_timeout_fallback_with_a_large_user_range(monkeypatch, capfd):
+    """The same fallback on 200 000 users: without clusters a member's user range --
+    and with it the LDS bitmap of the screen pass -- is four times the clustered one (25 KB
+    against 6 KB here, several LDS allocation granules apart); the relaunch must size its
+    dynamic LDS for the new geometry or the screen pass silently drops users."""
+    rng = np.random.default_rng(23)
+    R = sp.random(200000, 64, density=0.02, format="csr", random_state=rng, dtype=np.float32)
+    R.data[:] = 1.0 + np.floor(rng.random(R.nnz) * 5).astype(np.float32)
+    m = DeviceMatrix.from_scipy(R)
+    want, _ = m.learn(seed=1, kernel=KERNEL_TILE, cluster=1)
+    monkeypatch.setenv("SLIM_GPU_TEST_HOOKS", "1")
+    monkeypatch.setenv("SLIM_GPU_TEST_DROP_MEMBER", "1")
+    got, st = m.learn(seed=1, kernel=KERNEL_TILE, cluster=4)
+    assert "re-solving" in capfd.readouterr().err
+    assert want.nnz > 0 and got.nnz == want.nnz and maxdiff(got, want) == 0.0
+    m.close()
+
+
+def test_test_hooks_are_inert_without_the_master_switch(ml100k, monkeypatch, capfd):
+    """SLIM_GPU_TEST_DROP_MEMBER inherited from somebody's environment must not void launches:
+    the hooks act only together with SLIM_GPU_TEST_HOOKS=1."""
+    R, _ = ml100k
+    m = DeviceMatrix.from_scipy(R)
+    monkeypatch.delenv("SLIM_GPU_TEST_HOOKS", raising=False)
+    monkeypatch.setenv("SLIM_GPU_TEST_DROP_MEMBER", "1")
+    got, st = m.learn(seed=1, kernel=KERNEL_TILE, cluster=4, col_begin=0, col_end=128)
+    assert "re-solving" not in capfd.readouterr().err and got.nnz > 0
     m.close()
 
 
@@ -277,3 +309,23 @@ def test_bench_multi_rank_branch(scaling):
     assert out["value"] > 0 and out["unit"] == "item-columns/s"
     assert out["config"]["columns_per_step"] == 1683
     assert out["roofline"]["nnzW"] > 0
+
+
+@pytest.mark.timeout(420, method="thread")
+def test_bench_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the
+    one-rank-per-GPU job itself.  On a one-GPU box the two ranks share the device over gloo."""
+    import json
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--workload", "ml100k", "--backend", backend, "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    assert out["ranks"]["world"] == 2 and len(out["ranks"]["kernel_ms_per_rank"]) == 2
+    assert all(v > 0 for v in out["ranks"]["kernel_ms_per_rank"])

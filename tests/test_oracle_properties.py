@@ -103,3 +103,22 @@ def test_oracle_admm_against_a_numpy_restatement():
     assert np.abs(W - Wn.astype(np.float32)).max() <= 1e-6
     assert W.min() >= 0 and np.abs(np.diag(W)).max() <= 1e-3
     assert (W > 0).sum() > m
+
+
+def test_tile_walk_warm_start_reaches_the_per_item_warm_start(ml100k):
+    """The tile walk's warm start (estimate.c:453-464 + cd.c:108-110 in oracle_learn_cd_tile_warm)
+    against the per-item restatement's: from the same previous model both reach the same point at
+    a tight tolerance, in fewer sweeps than a cold start; restarted from its own solution the
+    walk needs one sweep."""
+    R, _ = ml100k
+    first = O.learn_cd(R, l1r=2.0, l2r=1.0, order=O.ORDER_PERM, seed=1, aty=O.ATY_GRAM, nthreads=8)
+    kw = dict(l1r=1.0, l2r=0.5, optTol=1e-13, maxniters=100000, nthreads=8)
+    a = O.learn_cd(R, order=O.ORDER_PERM, seed=2, aty=O.ATY_GRAM, imodel=first, **kw)
+    b, sb, _, _ = O.learn_cd_tile(R, seed=2, imodel=first, return_stats=True, **kw)
+    c, sc, _, _ = O.learn_cd_tile(R, seed=2, return_stats=True, **kw)
+    d = abs(a - b)
+    assert (float(d.max()) if d.nnz else 0.0) <= 2e-5
+    assert sb["sweeps"].sum() < sc["sweeps"].sum()
+    sol = O.learn_cd_tile(R, seed=1, nthreads=8)
+    _, s2, _, _ = O.learn_cd_tile(R, seed=1, nthreads=8, imodel=sol, return_stats=True)
+    assert s2["sweeps"].mean() <= 1.01
