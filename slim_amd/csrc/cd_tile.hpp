@@ -107,6 +107,12 @@ __device__ __forceinline__ float row_bcast(float v, int n) {
   return __int_as_float(row_bcast(__float_as_int(v), n));
 }
 
+// load from a uniform base + a 32-bit byte offset of the lane (global_load ..., v_off, s[base])
+template <class T>
+__device__ __forceinline__ T ld_off(const void* base, const uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 typedef unsigned long long tile_gran_t;
 
 __device__ __forceinline__ void gran_store(tile_gran_t* p, uint32_t epoch, float v) {
@@ -149,6 +155,8 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
   __shared__ float s_red[2][NW][P];
   __shared__ int s_item[P];
   __shared__ int s_na[P];
+  __shared__ int s_maxit[P], s_niters[P], s_conv[P];
+  __shared__ unsigned long long s_D[P], s_U[P];
   __shared__ int s_grp, s_nunion;
   __shared__ float s_tot[2][P];
   __shared__ int s_abort;
@@ -278,7 +286,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     {
       // (x needs no clearing: the active-set pass below assigns every entry)
       float4* r4 = reinterpret_cast<float4*>(r);
-      const int64_t nr4 = (int64_t)(uend - ubase) * (P / 4);
+      const int64_t nr4 = (int64_t)(uend - ubase + 1) * (P / 4);  // + the spare line (see visit)
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int64_t k = tid; k < nr4; k += NT) r4[k] = z;
       for (int k = tid; k < S.bm_words; k += NT) s_bits[k] = 0u;
@@ -517,16 +525,25 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     __syncthreads();
     const int nunion = s_nunion;
 
-    // -- per-problem state, replicated in every lane that serves problem q
+    // -- per-problem state: "done" replicated in every lane that serves problem q; what the
+    //    visit loop only accumulates or rarely reads (traffic counters, sweep cap and count)
+    //    lives in LDS, kept by the lanes 0 .. P-1 of wavefront 0 -- registers that stay live
+    //    across the visit loop are what the two gather buffers of a visit compete with
     const int item_q = s_item[q];
-    int maxit_q = 0;
-    if (item_q >= 0) {
-      const int64_t cap = 50 * (colptr[item_q + 1] - colptr[item_q]);  // estimate.c:448-449
-      maxit_q = cap < (int64_t)S.maxniters ? (int)cap : S.maxniters;
-    }
     bool done_q = item_q < 0;
-    int niters_q = 0, conv_q = 0;
-    int64_t D_q = 0, U_q = 0;
+    if (tid < P) {
+      int maxit = 0;
+      if (item_q >= 0) {
+        const int64_t cap = 50 * (colptr[item_q + 1] - colptr[item_q]);  // estimate.c:448-449
+        maxit = cap < (int64_t)S.maxniters ? (int)cap : S.maxniters;
+      }
+      s_maxit[tid] = maxit;
+      s_niters[tid] = 0;
+      s_conv[tid] = 0;
+      s_D[tid] = 0;
+      s_U[tid] = 0;
+    }
+    __syncthreads();
     int buf = 0;
     // PROFILE: [0] loads of the dot, [1] reduce + barrier, [2] update math, [3] stores issued,
     // [4] closing barrier, [5] visits, [6] visits with an update
@@ -549,6 +566,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     // slice
     constexpr int NR = P / 16;  // id / value registers per 64-nnz block (see row_bcast)
     const int ent0 = slot * P + (lane & 15);  // block entry this lane loads into register 0
+    const int udummy = uend - ubase;  // the spare line behind this member's user range (always 0)
     int pf_id[NR];
     float pf_v[NR];
 #pragma unroll
@@ -565,68 +583,92 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       const bool part = live && tile_active(xi);
       if (!__any(part)) return;
       constexpr int64_t CH = 64 * NW;  // nnz per workgroup chunk
-      int idreg[NR];
-      float vreg[NR];
-      float r_c[STEPS];
-      int nhere = 0;  // valid nnz of this wavefront's 64-block in the current chunk
-      int nloc = 0;   // ... of this lane group's P entries of it
+      // One 64-nnz block of this wavefront: ids / values (row_bcast layout), the gathered
+      // residuals, nh = valid nnz of the block.  Two
+      // blocks alternate: the gathers of the next block of a slice are issued before the
+      // current one is consumed, so that a slice of several chunks is one stream of requests
+      // instead of one memory round trip per chunk (ids, then lines).
+      struct Blk {
+        int id[NR];
+        float v[NR];
+        float r[STEPS];
+        int nh;
+      };
+      Blk A, B;
       // this wavefront's 64 consecutive nnz of chunk c0: one coalesced request per array and
-      // register (the rows of a lane group load the same 16 entries)
-      auto load_ids = [&](const int64_t c0) {
+      // register (the rows of a lane group load the same 16 entries).  Entries past the end of
+      // the slice become (user = the spare line behind this member's range, which holds 0 and
+      // stays 0; value 0): gathers, dot and write-back then need no predication at all.
+      auto load_ids = [&](Blk& b, const int64_t c0) {
         const int64_t b0 = c0 + 64 * wave;
         const int64_t left = e - b0;
-        nhere = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
-        nloc = nhere - slot * P;
+        b.nh = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
         if (HI && c0 == pf_here) {  // requested during the previous visit
 #pragma unroll
           for (int k = 0; k < NR; ++k) {
-            idreg[k] = pf_id[k];
-            vreg[k] = pf_v[k];
+            b.id[k] = pf_id[k];
+            b.v[k] = pf_v[k];
           }
           pf_here = -1;  // (pf_id is reused for the next visit before this block is re-read)
         } else {
+          // unconditional loads of the raw entries (a load under a condition makes the number
+          // of requests in flight path-dependent, and the compiler then waits for ALL of them
+          // where it only needs the oldest): uniform base, clamped into the array, + 32-bit
+          // lane offset; gather() turns them into line numbers when it needs them
+          const int64_t b0c = b0 < S.nnz_last ? b0 : S.nnz_last;
+          const int32_t* __restrict__ cb = ci + b0c;
+          const float* __restrict__ vb = cv + b0c;
 #pragma unroll
           for (int k = 0; k < NR; ++k) {
             const int ent = ent0 + 16 * k;
-            const bool ok = ent < nhere;
-            idreg[k] = ok ? ci[b0 + ent] - ubase : 0;
-            vreg[k] = ok ? (HAS_VAL ? cv[b0 + ent] : 1.0f) : 0.0f;
+            const uint32_t ec = (uint32_t)(ent < b.nh ? ent : 0);
+            b.id[k] = cb[ec];  // (raw user id: no arithmetic on it here, that would wait)
+            b.v[k] = HAS_VAL ? vb[ec] : 1.0f;
           }
         }
       };
       // gather the residual lines of the block: STEPS loads per lane in flight
-      auto gather = [&]() {
-        if (nhere > 0) {
+      auto gather = [&](Blk& b) {
+        {
+          // raw user ids -> line numbers; entries past the slice -> the spare line, value 0
 #pragma unroll
-          for (int j = 0; j < STEPS; ++j) {
-            const int u = row_bcast(idreg[j >> 4], j & 15);
-            r_c[j] = 0.0f;
-            if (j < nloc)
-              r_c[j] = *reinterpret_cast<const float*>(rb + (((uint32_t)u * (uint32_t)(4 * P)) | qoff));
+          for (int k = 0; k < NR; ++k) {
+            const bool ok = ent0 + 16 * k < b.nh;
+            b.id[k] = ok ? b.id[k] - ubase : udummy;
+            b.v[k] = ok ? b.v[k] : 0.0f;
           }
 #pragma unroll
-          for (int j = 0; j < STEPS; ++j) pin(r_c[j]);
+          for (int j = 0; j < STEPS; ++j) {
+            const int u = row_bcast(b.id[j >> 4], j & 15);
+            b.r[j] = *reinterpret_cast<const float*>(rb + (((uint32_t)u * (uint32_t)(4 * P)) | qoff));
+            // (address -> load, one step at a time: hoisting the 32 address computations of a
+            // block above its loads costs 32 registers the second block needs)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // (no use of the values here: the block is consumed after the NEXT block's loads
+          // have been issued)
         }
       };
-      auto dot_block = [&]() -> float {
+      auto dot_block = [&](const Blk& b) -> float {
         float a = 0.0f;
-        if (nhere > 0) {
+        {
 #pragma unroll
-          for (int j = 0; j < STEPS; ++j)  // (entries past the slice were gathered as 0)
-            a += HAS_VAL ? row_bcast(vreg[j >> 4], j & 15) * r_c[j] : r_c[j];
+          for (int j = 0; j < STEPS; ++j)  // (entries past the slice gathered the spare line: 0)
+            a += HAS_VAL ? row_bcast(b.v[j >> 4], j & 15) * b.r[j] : b.r[j];
         }
         return a;
       };
-      // whole lines: every problem's value of the user is written back
-      auto scatter = [&](const float d) {
-        if (nhere > 0) {
+      // whole lines: every problem's value of the user is written back (entries past the slice
+      // write 0 - d * 0 to the spare line)
+      auto scatter = [&](const Blk& b, const float d) {
+        {
 #pragma unroll
           for (int j = 0; j < STEPS; ++j) {
-            const int u = row_bcast(idreg[j >> 4], j & 15);
-            const float v = HAS_VAL ? row_bcast(vreg[j >> 4], j & 15) : 1.0f;
-            if (j < nloc)
-              *reinterpret_cast<float*>(rbw + (((uint32_t)u * (uint32_t)(4 * P)) | qoff)) =
-                  r_c[j] - d * v;
+            const int u = row_bcast(b.id[j >> 4], j & 15);
+            const float v = row_bcast(b.v[j >> 4], j & 15);
+            *reinterpret_cast<float*>(rbw + (((uint32_t)u * (uint32_t)(4 * P)) | qoff)) =
+                b.r[j] - d * v;
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       };
@@ -638,9 +680,9 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         const float d = (part && (xi > kEps || xi < -kEps)) ? xi : 0.0f;
         if (!__any(d != 0.0f)) return;
         for (int64_t c = s; c < e; c += CH) {
-          load_ids(c);
-          gather();
-          scatter(d);
+          load_ids(A, c);
+          gather(A);
+          scatter(A, d);
         }
         __syncthreads();
         return;
@@ -649,13 +691,38 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       const uint64_t p0 = tick();
       float acc = 0.0f;
       int64_t c0 = s;
-      for (; c0 + CH < e; c0 += CH) {
-        load_ids(c0);
-        gather();
-        acc += dot_block();
+      // The chunks of the slice alternate between the two blocks so that the last one lands in
+      // A (it stays in registers for the update): with an even number of chunks the first one
+      // is consumed on its own, the others pairwise -- the gathers of chunk k+1 are in flight
+      // before chunk k is summed.
+      const int64_t nchunks = e > s ? (e - s + CH - 1) / CH : 1;
+      // a wavefront beyond the end of a one-chunk slice has nothing to do (one branch around
+      // the whole stream; inside it every load is unconditional)
+      const bool mine = s + 64 * wave < e;
+      if (mine) {
+        if ((nchunks & 1) == 0) {
+          load_ids(A, c0);
+          gather(A);
+          acc += dot_block(A);
+          c0 += CH;
+        }
+        // an odd number of chunks b_0 .. b_2m is left: even ones in A, odd ones in B.  Loads
+        // complete in issue order, so the ids of a chunk are requested BEFORE the gathers of
+        // the chunk ahead of it -- waiting for them then does not drain those gathers:
+        //   ids(k+2), lines(k+1), [sum k], ids(k+3), lines(k+2), [sum k+1], ...
+        load_ids(A, c0);
+        load_ids(B, c0 + CH);  // (past the end of the slice: entries go to the spare line)
+        gather(A);
+        while (c0 + CH < e) {
+          load_ids(A, c0 + 2 * CH);  // A's ids are free once its gathers are issued
+          gather(B);
+          acc += dot_block(A);
+          load_ids(B, c0 + 3 * CH);
+          gather(A);
+          acc += dot_block(B);
+          c0 += 2 * CH;
+        }
       }
-      load_ids(c0);  // last chunk: kept in registers for the update
-      gather();
       // (sn_v / nn_v are still in flight when the visit starts: made uniform only here.)  The
       // loads are unconditional instructions with a clamped address -- lanes past the slice hold
       // garbage that load_ids never looks at -- so that exactly one (two with values) load is in
@@ -669,7 +736,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         for (int k = 0; k < NR; ++k) {
           int64_t jj = sn + 64 * wave + ent0 + 16 * k;
           jj = jj < S.nnz_last ? jj : S.nnz_last;
-          pf_id[k] = ci[jj] - ubase;
+          pf_id[k] = ci[jj];
           pf_v[k] = HAS_VAL ? cv[jj] : 1.0f;
         }
         pf_at = (nn > 0 && S.hi_prefetch) ? sn : -1;
@@ -679,7 +746,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       float d = 0.0f, nx = xi;
       uint64_t p2 = p1;
       {
-        acc += dot_block();
+        if (mine) acc += dot_block(A);
         if (SL == 4) acc += __shfl_xor(acc, 16);
         acc += __shfl_xor(acc, 32);
         if (slot == 0) s_part[buf][wave][q] = acc;
@@ -699,20 +766,35 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           d = 0.0f;
           nx = xi;
         } else {
-          D_q += len;
           dlt += (nx - xi) * (nx - xi);
-          if (d != 0.0f) U_q += len;
+          if (tid < P) {  // traffic counters of SURVEY.md 8(d)
+            s_D[q] += (unsigned long long)len;
+            if (d != 0.0f) s_U[q] += (unsigned long long)len;
+          }
         }
       }
       const bool upd = __any(d != 0.0f);
       const bool xch = __any(part && nx != xi);
       const uint64_t p3 = tick();
-      if (upd) {
-        scatter(d);
-        for (int64_t c = s; c < c0; c += CH) {  // earlier chunks: re-read (L2 / Infinity Cache)
-          load_ids(c);
-          gather();
-          scatter(d);
+      if (upd && mine) {
+        scatter(A, d);  // the last chunk: still in registers
+        // earlier chunks: read again (L2 / Infinity Cache); the ids of the next chunk are
+        // requested before the lines of the current one are waited for
+        if (s < c0) {
+          load_ids(A, s);
+          for (int64_t c = s; c < c0; c += CH) {
+            gather(A);
+            if (c + CH < c0) load_ids(B, c + CH);
+            scatter(A, d);
+            if (c + CH < c0) {
+#pragma unroll
+              for (int k = 0; k < NR; ++k) {
+                A.id[k] = B.id[k];
+                A.v[k] = B.v[k];
+              }
+              A.nh = B.nh;
+            }
+          }
         }
       }
       if (xch && wave == 0 && slot == 0 && part && nx != xi) x[(int64_t)i * P + q] = nx;
@@ -778,13 +860,13 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           for (;;) {
             const int64_t left = re - b;
             const int nh = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
-            const int nl = nh - slot * P;  // valid entries of this lane group
             int id[NR];
             float v[NR];
 #pragma unroll
-            for (int k = 0; k < NR; ++k) {
-              id[k] = id_n[k];
-              v[k] = v_n[k];
+            for (int k = 0; k < NR; ++k) {  // entries past the row: item 0 with value 0
+              const bool ok = ent0 + 16 * k < nh;
+              id[k] = ok ? id_n[k] : 0;
+              v[k] = ok ? v_n[k] : 0.0f;
             }
             // what comes after this block
             const bool row_end = left <= 64;
@@ -803,15 +885,14 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 #pragma unroll
             for (int j = 0; j < STEPS; ++j) {
               const int jj = row_bcast(id[j >> 4], j & 15);
-              xg[j] = 0.0f;
-              if (j < nl) xg[j] = xs[(int64_t)jj * P + q];
+              xg[j] = xs[(uint32_t)jj * (uint32_t)P + (uint32_t)q];
             }
 #pragma unroll
             for (int j = 0; j < STEPS; ++j) {
               const float xv = xg[j];
               // the coefficients that enter the residual (cd.c:27), inactive = -inf = none
               const float xe = (xv > kEps || (xv < -kEps && tile_active(xv))) ? xv : 0.0f;
-              acc += (HAS_VAL ? row_bcast(v[j >> 4], j & 15) : 1.0f) * xe;
+              acc += row_bcast(v[j >> 4], j & 15) * xe;
             }
             if (row_end) {
               if (SL == 4) acc += __shfl_xor(acc, 16);
@@ -839,9 +920,9 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 
     // -- sweeps (cd.c:112-139)
     for (int t = 0;; ++t) {
-      if (!done_q && t >= maxit_q) {  // loop exhausted without convergence: niters = t + 1
+      if (!done_q && t >= s_maxit[q]) {  // loop exhausted without convergence: niters = t + 1
         done_q = true;
-        niters_q = maxit_q + 1;
+        if (tid < P) s_niters[q] = s_maxit[q] + 1;
       }
       const bool live = !done_q;
       if (!__any(live) || s_abort) break;
@@ -850,35 +931,48 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       if (nunion > 0) {
         // software pipeline on the visit scalars: the column id is read two visits ahead, the
         // slice offsets / x row / norms one visit ahead (values stay in VGPRs until consumed)
-        int i_n1 = ul[perm_index(pc, 0u)];
-        int i_n2 = nunion > 1 ? ul[perm_index(pc, 1u)] : 0;
-        const int64_t* sp0 = csplit + (int64_t)i_n1 * (K + 1);
-        int64_t s_n = sp0[mk];
-        int n_n = (int)(sp0[mk + 1] - s_n), l_n = (int)(sp0[K] - sp0[0]);
-        float xi_n = x[(int64_t)i_n1 * P + q], cn_n = A.cnorm[i_n1], sq_n = A.csq[i_n1];
+        // (every address below = uniform base + 32-bit lane offset: the scalar-base form of
+        // the load, no 64-bit per-lane pointers kept across the visit)
+        const uint32_t sp_stride = (uint32_t)(K + 1) * 8u;
+        auto meta = [&](const int i1, int64_t& s_o, int& n_o, int& l_o, float& xi_o, float& cn_o,
+                        float& sq_o) {
+          const uint32_t so = (uint32_t)i1 * sp_stride;
+          const int64_t a = ld_off<int64_t>(csplit, so + (uint32_t)mk * 8u);
+          const int64_t b = ld_off<int64_t>(csplit, so + (uint32_t)mk * 8u + 8u);
+          const int64_t c = ld_off<int64_t>(csplit, so);
+          const int64_t d = ld_off<int64_t>(csplit, so + (uint32_t)K * 8u);
+          s_o = a;
+          n_o = (int)(b - a);
+          l_o = (int)(d - c);
+          xi_o = ld_off<float>(x, (uint32_t)i1 * (uint32_t)(4 * P) + qoff);
+          cn_o = ld_off<float>(A.cnorm, (uint32_t)i1 * 4u);
+          sq_o = ld_off<float>(A.csq, (uint32_t)i1 * 4u);
+        };
+        int i_n1 = ld_off<int>(ul, perm_index(pc, 0u) * 4u);
+        int i_n2 = nunion > 1 ? ld_off<int>(ul, perm_index(pc, 1u) * 4u) : 0;
+        int64_t s_n;
+        int n_n, l_n;
+        float xi_n, cn_n, sq_n;
+        meta(i_n1, s_n, n_n, l_n, xi_n, cn_n, sq_n);
         for (int p = 0; p < nunion; ++p) {
           const int i = uni(i_n1);
           const int64_t s = uni(s_n), e = s + uni(n_n), len = uni(l_n);
           const float xi = xi_n, cn = uni(cn_n), sq = uni(sq_n);
           if (p + 1 < nunion) {
             i_n1 = i_n2;
-            const int64_t* spn = csplit + (int64_t)i_n1 * (K + 1);
-            s_n = spn[mk];
-            n_n = (int)(spn[mk + 1] - s_n);
-            l_n = (int)(spn[K] - spn[0]);
-            xi_n = x[(int64_t)i_n1 * P + q];
-            cn_n = A.cnorm[i_n1];
-            sq_n = A.csq[i_n1];
-            if (p + 2 < nunion) i_n2 = ul[perm_index(pc, (uint32_t)(p + 2))];
+            meta(i_n1, s_n, n_n, l_n, xi_n, cn_n, sq_n);
+            if (p + 2 < nunion) i_n2 = ld_off<int>(ul, perm_index(pc, (uint32_t)(p + 2)) * 4u);
           }
           const bool more = p + 1 < nunion;
           visit(i, s, e, len, xi, cn, sq, live, dlt, 0, s_n, more ? n_n : 0);
         }
       }
       if (live && dlt < S.opt_tol) {  // cd.c:135-138
-        conv_q = 1;
         done_q = true;
-        niters_q = t + 1;
+        if (tid < P) {
+          s_conv[q] = 1;
+          s_niters[q] = t + 1;
+        }
       }
     }
 
@@ -946,10 +1040,9 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           wpos += __popcll(m);
         }
       }
-      // lane pq (slot 0, q == pq) holds this problem's replicated counters
-      const int niters = lane_bcast(niters_q, pq);
-      const int conv = lane_bcast(conv_q, pq);
-      const int64_t Dw = lane_bcast(D_q, pq), Uw = lane_bcast(U_q, pq);
+      const int niters = s_niters[pq];
+      const int conv = s_conv[pq];
+      const int64_t Dw = (int64_t)s_D[pq], Uw = (int64_t)s_U[pq];
       if (lane == 0) {
         if (!fits) atomicMax(S.overflow, 1);
         S.out_cnt[witem] = fits ? nz : -nz - 1;

@@ -735,9 +735,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     // tile width: 32 item columns per workgroup (128-byte residual lines) unless the row
     // offsets would overflow the kernel's 32-bit byte offsets
     int tileP = kernel == SLIMGPU_KERNEL_TILE16 ? 16 : 32;
-    if (kernel == SLIMGPU_KERNEL_TILE && (int64_t)nrows_pad * 128 >= (int64_t(1) << 32)) tileP = 16;
+    if (kernel == SLIMGPU_KERNEL_TILE && ((int64_t)nrows_pad + 64) * 128 >= (int64_t(1) << 32)) tileP = 16;
     bool use_tile = kernel == SLIMGPU_KERNEL_TILE || kernel == SLIMGPU_KERNEL_TILE16;
-    if (use_tile && (int64_t)nrows_pad * 4 * tileP >= (int64_t(1) << 32)) {
+    if (use_tile && ((int64_t)nrows_pad + 64) * 4 * tileP >= (int64_t(1) << 32)) {
       use_tile = false;  // > 67M users: fall back to one wavefront per item
       kernel = SLIMGPU_KERNEL_WAVE_HBM;
     }
@@ -856,7 +856,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       while (clusterK > 1 && wg_slots / clusterK < 1) clusterK /= 2;
       for (cluster_lg = 0; (1 << cluster_lg) < clusterK; ++cluster_lg) {}
       ensure_cluster_split(m, cluster_lg);
-      tile_r = (size_t)round_up(m->max_range_rows[cluster_lg], 64) * tileP;
+      // (+ 64 rows: the spare residual line behind a member's user range, cd_tile.hpp)
+      tile_r = (size_t)(round_up(m->max_range_rows[cluster_lg], 64) + 64) * tileP;
       tile_x = (size_t)ncols_pad * tileP;
       tile_u = (size_t)ncols_pad;
       nclusters = std::max(1, std::min(ngroups_all, wg_slots / clusterK));
@@ -877,7 +878,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         for (hi_lg = 0; (1 << hi_lg) < clusterHi; ++hi_lg) {}
         ensure_cluster_split(m, hi_lg);
         nclusters_hi = nclusters * clusterK / clusterHi;
-        tile_r = std::max(tile_r, (size_t)round_up(m->max_range_rows[hi_lg], 64) * tileP);
+        tile_r = std::max(tile_r, (size_t)(round_up(m->max_range_rows[hi_lg], 64) + 64) * tileP);
       }
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
