@@ -592,18 +592,50 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         int id[NR];
         float v[NR];
         float r[STEPS];
-        int nh;
+        int nh, nhv;  // valid nnz of the block the ids / the values belong to
       };
       Blk A, B;
       // this wavefront's 64 consecutive nnz of chunk c0: one coalesced request per array and
       // register (the rows of a lane group load the same 16 entries).  Entries past the end of
       // the slice become (user = the spare line behind this member's range, which holds 0 and
       // stays 0; value 0): gathers, dot and write-back then need no predication at all.
-      auto load_ids = [&](Blk& b, const int64_t c0) {
+      // (ids and values are requested separately: the ids of a block are free to be replaced
+      // once its gathers are issued, its values only after it has been summed)
+      auto load_idx = [&](Blk& b, const int64_t c0) {
         const int64_t b0 = c0 + 64 * wave;
         const int64_t left = e - b0;
         b.nh = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+        // unconditional loads of the raw entries (a load under a condition makes the number
+        // of requests in flight path-dependent, and the compiler then waits for ALL of them
+        // where it only needs the oldest): uniform base, clamped into the array, + 32-bit
+        // lane offset; gather() turns them into line numbers when it needs them
+        const int64_t b0c = b0 < S.nnz_last ? b0 : S.nnz_last;
+        const int32_t* __restrict__ cb = ci + b0c;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          const int ent = ent0 + 16 * k;
+          const uint32_t ec = (uint32_t)(ent < b.nh ? ent : 0);
+          b.id[k] = cb[ec];  // (raw user id: no arithmetic on it here, that would wait)
+        }
+      };
+      auto load_val = [&](Blk& b, const int64_t c0) {  // after load_idx of the same block
+        const int64_t b0 = c0 + 64 * wave;
+        const int64_t left = e - b0;
+        b.nhv = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+        const int64_t b0c = b0 < S.nnz_last ? b0 : S.nnz_last;
+        const float* __restrict__ vb = cv + b0c;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          const int ent = ent0 + 16 * k;
+          const uint32_t ec = (uint32_t)(ent < b.nhv ? ent : 0);
+          b.v[k] = HAS_VAL ? vb[ec] : 1.0f;
+        }
+      };
+      auto load_ids = [&](Blk& b, const int64_t c0) {
         if (HI && c0 == pf_here) {  // requested during the previous visit
+          const int64_t left = e - (c0 + 64 * wave);
+          b.nh = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+          b.nhv = b.nh;
 #pragma unroll
           for (int k = 0; k < NR; ++k) {
             b.id[k] = pf_id[k];
@@ -611,32 +643,22 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           }
           pf_here = -1;  // (pf_id is reused for the next visit before this block is re-read)
         } else {
-          // unconditional loads of the raw entries (a load under a condition makes the number
-          // of requests in flight path-dependent, and the compiler then waits for ALL of them
-          // where it only needs the oldest): uniform base, clamped into the array, + 32-bit
-          // lane offset; gather() turns them into line numbers when it needs them
-          const int64_t b0c = b0 < S.nnz_last ? b0 : S.nnz_last;
-          const int32_t* __restrict__ cb = ci + b0c;
-          const float* __restrict__ vb = cv + b0c;
-#pragma unroll
-          for (int k = 0; k < NR; ++k) {
-            const int ent = ent0 + 16 * k;
-            const uint32_t ec = (uint32_t)(ent < b.nh ? ent : 0);
-            b.id[k] = cb[ec];  // (raw user id: no arithmetic on it here, that would wait)
-            b.v[k] = HAS_VAL ? vb[ec] : 1.0f;
-          }
+          load_idx(b, c0);
+          load_val(b, c0);
         }
+      };
+      // values of the entries past the slice are 0 (idempotent)
+      auto mask_val = [&](Blk& b) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) b.v[k] = ent0 + 16 * k < b.nhv ? b.v[k] : 0.0f;
       };
       // gather the residual lines of the block: STEPS loads per lane in flight
       auto gather = [&](Blk& b) {
         {
-          // raw user ids -> line numbers; entries past the slice -> the spare line, value 0
+          // raw user ids -> line numbers; entries past the slice -> the spare line
 #pragma unroll
-          for (int k = 0; k < NR; ++k) {
-            const bool ok = ent0 + 16 * k < b.nh;
-            b.id[k] = ok ? b.id[k] - ubase : udummy;
-            b.v[k] = ok ? b.v[k] : 0.0f;
-          }
+          for (int k = 0; k < NR; ++k)
+            b.id[k] = ent0 + 16 * k < b.nh ? b.id[k] - ubase : udummy;
 #pragma unroll
           for (int j = 0; j < STEPS; ++j) {
             const int u = row_bcast(b.id[j >> 4], j & 15);
@@ -649,8 +671,9 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           // have been issued)
         }
       };
-      auto dot_block = [&](const Blk& b) -> float {
+      auto dot_block = [&](Blk& b) -> float {
         float a = 0.0f;
+        if (HAS_VAL) mask_val(b);
         {
 #pragma unroll
           for (int j = 0; j < STEPS; ++j)  // (entries past the slice gathered the spare line: 0)
@@ -660,7 +683,8 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       };
       // whole lines: every problem's value of the user is written back (entries past the slice
       // write 0 - d * 0 to the spare line)
-      auto scatter = [&](const Blk& b, const float d) {
+      auto scatter = [&](Blk& b, const float d) {
+        mask_val(b);
         {
 #pragma unroll
           for (int j = 0; j < STEPS; ++j) {
@@ -714,12 +738,14 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         load_ids(B, c0 + CH);  // (past the end of the slice: entries go to the spare line)
         gather(A);
         while (c0 + CH < e) {
-          load_ids(A, c0 + 2 * CH);  // A's ids are free once its gathers are issued
+          load_idx(A, c0 + 2 * CH);  // A's ids are free once its gathers are issued,
           gather(B);
           acc += dot_block(A);
-          load_ids(B, c0 + 3 * CH);
+          load_val(A, c0 + 2 * CH);  // its values once it has been summed
+          load_idx(B, c0 + 3 * CH);
           gather(A);
           acc += dot_block(B);
+          load_val(B, c0 + 3 * CH);
           c0 += 2 * CH;
         }
       }
@@ -793,6 +819,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
                 A.v[k] = B.v[k];
               }
               A.nh = B.nh;
+              A.nhv = B.nhv;
             }
           }
         }
