@@ -225,7 +225,10 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           for (int j = 0; j < MAXG; ++j) ok &= (uint32_t)(g[j] >> 32) == epoch;
           if (__all(ok) || aborted) break;
           if (t0 == 0) t0 = wall_clock64();
-          __builtin_amdgcn_s_sleep(1);
+          // (a partner that is late by more than a few round trips is polled at a lower rate:
+          // polls are fabric reads)
+          if (wall_clock64() - t0 > 2000ull) __builtin_amdgcn_s_sleep(64);
+          else __builtin_amdgcn_s_sleep(1);
           if (wall_clock64() - t0 > 1000000000ull) {  // 10 s at 100 MHz: give up, loudly
             aborted = true;
             s_abort = 1;
@@ -278,6 +281,11 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     const uint32_t gkey =
         (uint32_t)(((grp / PER) * S.shard_count + S.shard_index) * PER + grp % PER);
     const int nprob = (S.nwork - base) < P ? (S.nwork - base) : P;
+    // Screen sums of this tile kept from an earlier solve of the same columns (a model-selection
+    // grid solves every (l1, l2) pair over the same R: a_i . y does not depend on the pair):
+    // S.gram_mode 2 = read them instead of running the screen pass, 1 = record them
+    float* const gram_t = S.gram_mode != 0 ? S.gram + (int64_t)grp * S.x_stride : nullptr;
+    const bool cached = S.gram_mode == 2;
     if (tid < P) {
       s_item[tid] = tid < nprob ? S.order[base + tid] : -1;
       s_na[tid] = 0;
@@ -289,7 +297,8 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       const int64_t nr4 = (int64_t)(uend - ubase + 1) * (P / 4);  // + the spare line (see visit)
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int64_t k = tid; k < nr4; k += NT) r4[k] = z;
-      for (int k = tid; k < S.bm_words; k += NT) s_bits[k] = 0u;
+      if (!cached)
+        for (int k = tid; k < S.bm_words; k += NT) s_bits[k] = 0u;
     }
     __syncthreads();
 
@@ -308,7 +317,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           const int u = ci[j] - ubase;
           r[(int64_t)u * P + pq] = HAS_VAL ? cv[j] : 1.0f;
           const uint32_t bit = (uint32_t)u >> sh;
-          atomicOr(&s_bits[bit >> 5], 1u << (bit & 31));
+          if (!cached) atomicOr(&s_bits[bit >> 5], 1u << (bit & 31));
         }
       }
     }
@@ -324,7 +333,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     //    Gram-column form, sum over the item's users of their rows, needs one device-scope
     //    float atomic per touched (item, problem): 1.2 s of a 12.9 s median tile on C4, 7 s of
     //    the 27 s heaviest tile.)
-    {
+    if (!cached) {
       constexpr int GS = 8;  // gather steps in flight per lane (16: no gain, measured)
       for (int i = wave; i < ncols; i += NW) {
         const int64_t cs = uni(csplit[(int64_t)i * (K + 1) + mk]);
@@ -382,7 +391,8 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         if (slot == 0) part[(int64_t)i * P + q] = acc;  // one 128-byte line per column
       }
     }
-    cluster_barrier();  // every member's partial sums are published
+    if (!cached) cluster_barrier();  // every member's partial sums are published
+    else __syncthreads();
 
     // -- active sets: x = 0 for active, -inf for inactive
     if (FSLIM) {
@@ -406,7 +416,12 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         const int i = (int)(idx >> LOGP), qq = (int)(idx & (P - 1));
         const int it = s_item[qq];
         float a = 0.0f;
-        for (int k = 0; k < K; ++k) a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
+        if (cached) {
+          a = gram_t[idx];
+        } else {
+          for (int k = 0; k < K; ++k) a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
+          if (gram_t != nullptr && mk == 0) gram_t[idx] = a;
+        }
         float sim = kInactive;
         if (it >= 0 && i != it && a != 0.0f) {
           const float cn_i = A.cnorm[i];
@@ -471,8 +486,13 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         const int i = (int)(idx >> LOGP), qq = (int)(idx & (P - 1));
         const int it = s_item[qq];
         float a = 0.0f;  // members in rank order: the same sum on every member
-        for (int k = 0; k < K; ++k)
-          a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
+        if (cached) {
+          a = gram_t[idx];
+        } else {
+          for (int k = 0; k < K; ++k)
+            a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
+          if (gram_t != nullptr && mk == 0) gram_t[idx] = a;
+        }
         const bool act = it >= 0 && i != it && a > l1;
         x[idx] = act ? 0.0f : kInactive;
         if (act) atomicAdd(&s_na[qq], 1);

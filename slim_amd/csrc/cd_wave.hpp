@@ -103,6 +103,10 @@ struct SolveArgs {
   // tile kernel: 1 = undo the round-robin block -> XCD placement so that the members of a
   // cluster share an XCD (requires gridDim.x % 8 == 0); see tile_block_id()
   int32_t xcd_swizzle;
+  // tile kernel: screen sums a_i . y of every tile, [tile][ncols][P], kept across solves of the
+  // same columns (0: unused, 1: record, 2: read instead of running the screen pass)
+  float* gram;
+  int32_t gram_mode;
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;
   int64_t* out_off;

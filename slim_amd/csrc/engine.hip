@@ -61,6 +61,12 @@ struct slimgpu_matrix {
   };
   // copies of this matrix on other devices of the node (multi_gpu.cpp); owned by this handle
   std::vector<slimgpu_matrix*> replicas;
+  // screen sums (a_i . y for every column i and every item of a tile) of the most recent tile
+  // solve, reusable by the next solve of the same columns in the same geometry (model-selection
+  // grids: slim_mselect.c:99-113 solves every (l1, l2) pair over the same R)
+  Buf ws_gram;
+  std::vector<int32_t> gram_order;  // work list the sums belong to (empty: none recorded)
+  int gram_geom[6] = {0, 0, 0, 0, 0, 0};  // tileP, K, K_hi, nheavy, shard count, shard index
   Buf ws_order, ws_cnt, ws_off, ws_stat_i, ws_stat_l, ws_stat_f, ws_misc, ws_arena_i, ws_arena_v,
       ws_slab, ws_xslab, ws_ulist, ws_trace, ws_mailbox, ws_part, ws_icolptr, ws_icolind,
       ws_icolval;
@@ -425,7 +431,8 @@ void destroy(slimgpu_matrix* m) {
   for (slimgpu_matrix::Buf* b :
        {&m->ws_order, &m->ws_cnt, &m->ws_off, &m->ws_stat_i, &m->ws_stat_l, &m->ws_stat_f,
         &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_xslab, &m->ws_ulist,
-        &m->ws_trace, &m->ws_mailbox, &m->ws_part, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval})
+        &m->ws_trace, &m->ws_mailbox, &m->ws_part, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval,
+        &m->ws_gram})
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -903,7 +910,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int64_t* d_stl = ws_get<int64_t>(m->ws_stat_l, 3 * (size_t)ncols);
     float* d_stf = ws_get<float>(m->ws_stat_f, 2 * (size_t)ncols);
     // misc: [0] queue (int32) [1] overflow (int32) [2..3] cursor (u64)
-    int32_t* d_misc = ws_get<int32_t>(m->ws_misc, 6);  // [4] queue of the heavy phase
+    int32_t* d_misc = ws_get<int32_t>(m->ws_misc, 16);  // [4] queue of the heavy phase
     float* d_slab = nullptr;
     float* d_xslab = nullptr;
     int32_t* d_ulist = nullptr;
@@ -1012,6 +1019,30 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     std::vector<int64_t> fin_off((size_t)ncols, 0);
     int64_t fin_total = 0;
 
+    // screen-sum cache: read when this very work list was solved last time in this geometry,
+    // else record (if the [tiles][ncols][P] array fits comfortably next to everything else)
+    int gram_mode = 0;
+    float* d_gram = nullptr;
+    const int gram_geom_now[6] = {tileP, clusterK, nheavy > 0 ? clusterHi : 0, nheavy,
+                                  opt.shard_count, opt.shard_index};
+    if (use_tile && !std::getenv("SLIM_GPU_NO_GRAM")) {
+      const size_t ngroups0 = ((size_t)nwork + tileP - 1) / tileP;
+      const size_t need = ngroups0 * tile_x * sizeof(float);
+      if (!m->gram_order.empty() && m->gram_order == order && m->ws_gram.bytes >= need &&
+          std::equal(gram_geom_now, gram_geom_now + 6, m->gram_geom)) {
+        gram_mode = 2;
+        d_gram = static_cast<float*>(m->ws_gram.p);
+      } else {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (need <= (size_t(64) << 30) && need <= (free_b + m->ws_gram.bytes) / 2) {
+          m->gram_order.clear();  // (invalid while it is being rewritten)
+          d_gram = ws_get<float>(m->ws_gram, need / sizeof(float));
+          gram_mode = 1;
+        }
+      }
+    }
+
     bool cluster_fallback = false;
     for (int attempt = 0; attempt < 8 && !pending.empty(); ++attempt) {
       const int32_t npend = (int32_t)pending.size();
@@ -1019,7 +1050,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       float* d_av = ws_get<float>(m->ws_arena_v, (size_t)arena_cap);
       HIP_TRY(hipMemcpyAsync(d_order, pending.data(), sizeof(int32_t) * (size_t)npend,
                              hipMemcpyHostToDevice, stream));
-      HIP_TRY(hipMemsetAsync(d_misc, 0, sizeof(int32_t) * 6, stream));
+      HIP_TRY(hipMemsetAsync(d_misc, 0, sizeof(int32_t) * 16, stream));
       if (attempt > 0) nheavy = 0;  // a retry regroups what is left: plain clusters
 
       SolveArgs S;
@@ -1065,6 +1096,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.shard_index = opt.shard_index;
       S.nnz_last = m->nnz > 0 ? m->nnz - 1 : 0;
       S.xcd_swizzle = 0;
+      // (valid for the first launch over the whole work list only: a retry solves a subset,
+      // the fallback another geometry)
+      S.gram_mode = (attempt == 0 && !cluster_fallback) ? gram_mode : 0;
+      S.gram = d_gram;
       if (const char* e = std::getenv("SLIM_GPU_HI_PREFETCH")) S.hi_prefetch = std::atoi(e);
       if (use_tile)
         HIP_TRY(hipMemsetAsync(d_mailbox, 0, sizeof(unsigned long long) * mailbox_words, stream));
@@ -1198,6 +1233,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         set_error("SLIMGPU_Learn: a tile cluster timed out waiting for a member workgroup "
                   "(were all workgroups resident?)");
         return fail(SLIM_ERROR);
+      }
+      if (S.gram_mode == 1) {  // the launch completed: its screen sums are reusable
+        m->gram_order = order;
+        std::copy(gram_geom_now, gram_geom_now + 6, m->gram_geom);
       }
       unsigned long long cursor;
       std::memcpy(&cursor, h_misc + 2, sizeof(cursor));

@@ -403,6 +403,32 @@ def test_tile_kernel_warm_start_matches_oracle_tile_walk(fold, monkeypatch):
         m.close()
 
 
+def test_screen_sum_cache_changes_nothing(monkeypatch):
+    """A second solve of the same columns reads the screen sums a_i . y the first one recorded
+    (engine.hip: gram cache; what a model-selection grid does 45 times over one R) instead of
+    running the screen pass again: same model, bit for bit, as a handle that never saw the
+    matrix before -- cold and warm, l1 screen and FSLIM, clusters of 1 and 4."""
+    R = _random_ratings(40000, 150, 0.01, 3)
+    for geom in (dict(cluster=1), dict(cluster=4)):
+        m = DeviceMatrix.from_scipy(R)
+        first, _ = m.learn(l1r=3.0, l2r=1.0, seed=2, kernel=KERNEL_TILE, **geom)      # records
+        second, st2 = m.learn(l1r=1.0, l2r=0.5, seed=2, kernel=KERNEL_TILE, **geom)    # reads
+        warm, _ = m.learn(l1r=1.0, l2r=0.5, seed=2, kernel=KERNEL_TILE, imodel=first, **geom)
+        fs, _ = m.learn(l1r=1.0, l2r=0.5, seed=2, kernel=KERNEL_TILE, nnbrs=20, **geom)
+        m.close()
+        monkeypatch.setenv("SLIM_GPU_NO_GRAM", "1")
+        f = DeviceMatrix.from_scipy(R)
+        ref, st_ref = f.learn(l1r=1.0, l2r=0.5, seed=2, kernel=KERNEL_TILE, **geom)
+        ref_warm, _ = f.learn(l1r=1.0, l2r=0.5, seed=2, kernel=KERNEL_TILE, imodel=first, **geom)
+        ref_fs, _ = f.learn(l1r=1.0, l2r=0.5, seed=2, kernel=KERNEL_TILE, nnbrs=20, **geom)
+        f.close()
+        monkeypatch.delenv("SLIM_GPU_NO_GRAM")
+        assert second.nnz == ref.nnz and maxdiff(second, ref) == 0.0
+        assert warm.nnz == ref_warm.nnz and maxdiff(warm, ref_warm) == 0.0
+        assert fs.nnz == ref_fs.nnz and maxdiff(fs, ref_fs) == 0.0
+        assert st2["sweeps"] == st_ref["sweeps"]
+
+
 def test_tile_kernel_ratings_and_warm_start():
     R = _random_ratings(40000, 150, 0.01, 3)   # 4*(40000+300) > 64 KiB: no LDS kernel
     m = DeviceMatrix.from_scipy(R)
