@@ -57,8 +57,11 @@ def parse_args():
     ap.add_argument("--kernel", type=int, default=0, help="slimgpu_kernel_et (0 = auto)")
     ap.add_argument("--cluster", type=int, default=int(os.environ.get("SLIM_BENCH_CLUSTER", "0")),
                     help="tile kernels: workgroups per tile, 1/2/4/8 (0 = auto)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0,
-                    help="CPU-baseline budget per measured mode (0 disables the leg)")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0,
+                    help="CPU-baseline budget of each one-thread mode (0 disables the whole leg)")
+    ap.add_argument("--cpu-columns", type=int, default=int(os.environ.get("SLIM_BENCH_CPU_COLUMNS", "256")),
+                    help="columns of the last step timed by the parallel CPU-baseline mode (rounds of "
+                         "--cpu-threads columns each)")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("SLIM_BENCH_CPU_THREADS", "32")),
                     help="threads of the parallel CPU-baseline modes (0 = all physical cores; on "
                          "the 128-core boxes of this pool one round then takes ~3 minutes)")
@@ -430,7 +433,7 @@ def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts,
 
     # one column on one thread sizes everything else
     _, t1 = timed(pool[:1], 1, gram)
-    n1 = int(max(1, min(2, args.cpu_seconds // max(t1, 1e-3))))
+    n1 = int(max(1, min(8, args.cpu_seconds // max(t1, 1e-3))))
     res = {}
     _, t = timed(pool[:n1], 1, gram)
     res["gram_localprng_1thread"] = {"value": n1 / t, "columns": n1, "seconds": round(t, 3), "threads": 1}
@@ -441,14 +444,27 @@ def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts,
     # 0.73 col/s on 128 threads against ~2.5 on 32, profiles/r02/cpu_baseline_128threads.txt --
     # and one such round takes three minutes); a round takes longer than one column alone, so
     # the round count comes from a first round
+    # SURVEY.md 8(d) asks for a sample of >= 512 columns; --cpu-columns (default 256, ~100 s on
+    # 32 threads) are timed round by round so that the spread is visible: `value` is all
+    # columns over all seconds, `rounds` lists every round's rate
     use = max(1, min(args.cpu_threads or cores, cores, span))
-    Wc, t = timed(pool[:use], use, gram)
-    rounds = int(max(1, min(span // use, 2, (args.cpu_seconds / 2) // max(t, 1e-3))))
+    rounds = int(max(1, min(span // use, -(-max(args.cpu_columns, use) // use))))
     sample = pool[:use * rounds]
-    if rounds > 1:
-        Wc, t = timed(sample, use, gram)
+    parts, t = [], 0.0
+    round_rates = []
+    for k in range(rounds):
+        Wk, tk = timed(sample[k * use:(k + 1) * use], use, gram)
+        parts.append(Wk)
+        t += tk
+        round_rates.append(round(use / tk, 3))
+    Wc = parts[0]
+    for Wk in parts[1:]:
+        Wc = Wc + Wk   # disjoint columns
+    srt = sorted(round_rates)
     res["gram_localprng_allcores"] = {"value": sample.size / t, "columns": int(sample.size),
-                                      "seconds": round(t, 3), "threads": use}
+                                      "seconds": round(t, 3), "threads": use,
+                                      "rounds": round_rates, "round_min": srt[0],
+                                      "round_median": srt[len(srt) // 2], "round_max": srt[-1]}
     _, tf = timed(pool[:use], use, faithful)
     res["fullscan_rand_allcores"] = {"value": use / tf, "columns": use, "seconds": round(tf, 3),
                                      "threads": use}

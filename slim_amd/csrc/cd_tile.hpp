@@ -743,7 +743,18 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       // a wavefront beyond the end of a one-chunk slice has nothing to do (one branch around
       // the whole stream; inside it every load is unconditional)
       const bool mine = s + 64 * wave < e;
-      if (mine) {
+      if (mine && HAS_VAL) {
+        // valued matrices: one block at a time (the values of two blocks on top of their
+        // residual lines do not fit the register budget: measured as 40 spills in this loop)
+        for (; c0 + CH < e; c0 += CH) {
+          load_ids(A, c0);
+          gather(A);
+          acc += dot_block(A);
+        }
+        load_ids(A, c0);
+        gather(A);
+      }
+      if (mine && !HAS_VAL) {
         if ((nchunks & 1) == 0) {
           load_ids(A, c0);
           gather(A);

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <numeric>
@@ -1314,6 +1315,63 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       colptr[c + 1] = colptr[c] + n;
     }
     slim_csr_t* model = model_from_columns(ncols, colptr, colind, colval, row_view);
+
+    if (opt.dbglvl & SLIM_DBG_PROGRESS) {
+      // estimate.c:507-514: one line per solved column, in column order (the reference prints
+      // them as its threads finish).  Everything but "a0s" comes from the counters the kernels
+      // return; a0s (ComputeAvgZeroScore, estimate.c:627-662: the mean of the 10 largest
+      // predicted scores among the users that did NOT rate the item) is a diagnostic that costs
+      // one pass over R per column -- done here on the host, as the reference does, because
+      // this switch is for eyeballing small runs.  tmr: the reference prints a timer it never
+      // starts (estimate.c:377,514).
+      std::vector<int64_t> hp((size_t)m->nrows + 1);
+      std::vector<int32_t> hi((size_t)std::max<int64_t>(m->nnz, 1));
+      std::vector<float> hv(m->binary ? 0 : (size_t)std::max<int64_t>(m->nnz, 1));
+      std::vector<int64_t> hcp((size_t)ncols + 1);
+      HIP_TRY(hipMemcpy(hp.data(), m->d_rowptr, sizeof(int64_t) * hp.size(), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(hcp.data(), m->d_colptr, sizeof(int64_t) * hcp.size(), hipMemcpyDeviceToHost));
+      if (m->nnz > 0) {
+        HIP_TRY(hipMemcpy(hi.data(), m->d_rowind, sizeof(int32_t) * (size_t)m->nnz, hipMemcpyDeviceToHost));
+        if (!m->binary)
+          HIP_TRY(hipMemcpy(hv.data(), m->d_rowval, sizeof(float) * (size_t)m->nnz, hipMemcpyDeviceToHost));
+      }
+      std::vector<int32_t> sorted = requested;
+      std::sort(sorted.begin(), sorted.end());
+      std::vector<double> xd((size_t)ncols, 0.0);
+      std::vector<char> rated((size_t)m->nrows, 0);
+      std::vector<float> scores;
+      for (int32_t c : sorted) {
+        double nrm1 = 0.0;
+        for (ssize_t k = colptr[c]; k < colptr[c + 1]; ++k) {
+          xd[(size_t)colind[k]] = colval[k];
+          nrm1 += colval[k];
+        }
+        scores.clear();
+        for (int32_t u = 0; u < m->nrows; ++u) {
+          bool has = false;
+          double r = 0.0;
+          for (int64_t e = hp[(size_t)u]; e < hp[(size_t)u + 1]; ++e) {
+            if (hi[(size_t)e] == c) has = true;
+            r += xd[(size_t)hi[(size_t)e]] * (m->binary ? 1.0 : (double)hv[(size_t)e]);
+          }
+          if (!has) scores.push_back((float)r);
+        }
+        const size_t ntop = std::min<size_t>(10, scores.size());
+        std::partial_sort(scores.begin(), scores.begin() + (ptrdiff_t)ntop, scores.end(),
+                          std::greater<float>());
+        float a0 = 0.0f;
+        for (size_t k = 0; k < ntop; ++k) a0 += scores[k];
+        for (ssize_t k = colptr[c]; k < colptr[c + 1]; ++k) xd[(size_t)colind[k]] = 0.0;
+        std::printf("Col: %5d %5zd rs: %3d nits: %4d nnz: %4d rsd: %.2le obj: %.2le ff: %.3lf nrm1: "
+                    "%.3lf a0s: %.3lf tmr: %.2le\n",
+                    c, (ssize_t)(hcp[(size_t)c + 1] - hcp[(size_t)c]), cs.conv[(size_t)c],
+                    cs.sweeps[(size_t)c], (int)(colptr[c + 1] - colptr[c]), (double)h_err[(size_t)c],
+                    (double)h_obj[(size_t)c],
+                    h_obj[(size_t)c] != 0 ? (double)h_err[(size_t)c] / (double)h_obj[(size_t)c] : 0.0,
+                    nrm1, ntop ? (double)a0 / (double)ntop : 0.0, 0.0);
+      }
+      std::fflush(stdout);
+    }
 
     st.ncols_solved = nwork;
     st.kernel = kernel;
