@@ -672,23 +672,27 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 #pragma unroll
         for (int k = 0; k < NR; ++k) b.v[k] = ent0 + 16 * k < b.nhv ? b.v[k] : 0.0f;
       };
+      // raw user ids -> line numbers; entries past the slice -> the spare line (binary
+      // matrices: the values are 1 for the entries of the slice)
+      auto fix_ids = [&](Blk& b) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          b.id[k] = ent0 + 16 * k < b.nh ? b.id[k] - ubase : udummy;
+          if (!HAS_VAL) b.v[k] = 1.0f;
+        }
+        if (!HAS_VAL) b.nhv = b.nh;
+      };
       // gather the residual lines of the block: STEPS loads per lane in flight
       auto gather = [&](Blk& b) {
-        {
-          // raw user ids -> line numbers; entries past the slice -> the spare line
+        fix_ids(b);
 #pragma unroll
-          for (int k = 0; k < NR; ++k)
-            b.id[k] = ent0 + 16 * k < b.nh ? b.id[k] - ubase : udummy;
-#pragma unroll
-          for (int j = 0; j < STEPS; ++j) {
-            const int u = row_bcast(b.id[j >> 4], j & 15);
-            b.r[j] = *reinterpret_cast<const float*>(rb + (((uint32_t)u * (uint32_t)(4 * P)) | qoff));
-            // (address -> load, one step at a time: hoisting the 32 address computations of a
-            // block above its loads costs 32 registers the second block needs)
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          // (no use of the values here: the block is consumed after the NEXT block's loads
-          // have been issued)
+        for (int j = 0; j < STEPS; ++j) {
+          const int u = row_bcast(b.id[j >> 4], j & 15);
+          b.r[j] = *reinterpret_cast<const float*>(rb + (((uint32_t)u * (uint32_t)(4 * P)) | qoff));
+          // (address -> load, one step at a time: hoisting the 32 address computations of a
+          // block above its loads costs 32 registers the second block needs.  No use of the
+          // values here: the block is consumed after the NEXT block's loads have been issued.)
+          __builtin_amdgcn_sched_barrier(0);
         }
       };
       auto dot_block = [&](Blk& b) -> float {
@@ -754,31 +758,39 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         load_ids(A, c0);
         gather(A);
       }
+      // Binary matrices: two blocks in flight.  Chunk k of the slice lands in A when
+      // (nchunks - 1 - k) is even, else in B, so that the LAST chunk ends up in A and the lines
+      // of the one before it in B: both stay in registers for the update (a slice of one or two
+      // chunks is never gathered twice).  Loads complete in issue order, so the ids of a chunk
+      // are requested BEFORE the gathers of the chunk ahead of it (a block's id registers are
+      // free as soon as its gathers are issued) -- waiting for them then does not drain those
+      // gathers:   ids(k+2), lines(k+1), [sum k], ids(k+3), lines(k+2), [sum k+1], ...
       if (mine && !HAS_VAL) {
-        if ((nchunks & 1) == 0) {
+        if (nchunks & 1) {  // b0 -> A
           load_ids(A, c0);
+          load_idx(B, c0 + CH);
           gather(A);
-          acc += dot_block(A);
           c0 += CH;
-        }
-        // an odd number of chunks b_0 .. b_2m is left: even ones in A, odd ones in B.  Loads
-        // complete in issue order, so the ids of a chunk are requested BEFORE the gathers of
-        // the chunk ahead of it -- waiting for them then does not drain those gathers:
-        //   ids(k+2), lines(k+1), [sum k], ids(k+3), lines(k+2), [sum k+1], ...
-        load_ids(A, c0);
-        load_ids(B, c0 + CH);  // (past the end of the slice: entries go to the spare line)
-        gather(A);
-        while (c0 + CH < e) {
-          load_idx(A, c0 + 2 * CH);  // A's ids are free once its gathers are issued,
+        } else {  // b0 -> B, b1 -> A
+          load_ids(B, c0);
+          load_idx(A, c0 + CH);
           gather(B);
-          acc += dot_block(A);
-          load_val(A, c0 + 2 * CH);  // its values once it has been summed
-          load_idx(B, c0 + 3 * CH);
+          load_idx(B, c0 + 2 * CH);
           gather(A);
           acc += dot_block(B);
-          load_val(B, c0 + 3 * CH);
           c0 += 2 * CH;
         }
+        // here: A in flight = the chunk at c0 - CH, B's ids = those of the chunk at c0
+        while (c0 < e) {
+          load_idx(A, c0 + CH);
+          gather(B);
+          acc += dot_block(A);
+          load_idx(B, c0 + 2 * CH);
+          gather(A);
+          acc += dot_block(B);
+          c0 += 2 * CH;
+        }
+        c0 -= CH;  // start of the last chunk (in A)
       }
       // (sn_v / nn_v are still in flight when the visit starts: made uniform only here.)  The
       // loads are unconditional instructions with a clamped address -- lanes past the slice hold
@@ -835,15 +847,24 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       const uint64_t p3 = tick();
       if (upd && mine) {
         scatter(A, d);  // the last chunk: still in registers
-        // earlier chunks: read again (L2 / Infinity Cache); the ids of the next chunk are
-        // requested before the lines of the current one are waited for
-        if (s < c0) {
+        int64_t stop = c0;  // chunks [s, stop) are read again (L2 / Infinity Cache)
+        if (!HAS_VAL && nchunks >= 2) {
+          // binary: so are the LINES of the chunk before it; its ids are read again (4 bytes
+          // per nnz from L2 instead of a 128-byte line per nnz)
+          stop = c0 - CH;
+          load_idx(B, stop);
+          fix_ids(B);
+          scatter(B, d);
+        }
+        // the ids of the next chunk are requested before the lines of the current one are
+        // waited for
+        if (s < stop) {
           load_ids(A, s);
-          for (int64_t c = s; c < c0; c += CH) {
+          for (int64_t c = s; c < stop; c += CH) {
             gather(A);
-            if (c + CH < c0) load_ids(B, c + CH);
+            if (c + CH < stop) load_ids(B, c + CH);
             scatter(A, d);
-            if (c + CH < c0) {
+            if (c + CH < stop) {
 #pragma unroll
               for (int k = 0; k < NR; ++k) {
                 A.id[k] = B.id[k];
