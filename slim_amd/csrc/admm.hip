@@ -262,6 +262,22 @@ slim_csr_t* learn_admm(int32_t nrows, const ssize_t* rowptr, const int32_t* rowi
   for (int64_t k = 0; k < nnz; ++k)
     if (rowind[k] < 0) return fail(SLIM_ERROR_INPUT, "SLIM_Learn(admm): negative item id");
   const int64_t n2 = (int64_t)m * m;
+  {
+    // the same input rules as the CD path (engine.hip staging: offsets, id range, no repeated
+    // (user, item) pair -- the reference would count a repeated pair twice in R^T R and once
+    // per entry in the norms; neither solver defines a problem for it): a repeated item id
+    // inside a row is found with one marker pass per row
+    std::vector<int32_t> seen((size_t)m, -1);
+    for (int32_t u = 0; u < nrows; ++u) {
+      if (rowptr[u] > rowptr[u + 1] || rowptr[u] < 0 || rowptr[u + 1] > nnz)
+        return fail(SLIM_ERROR_INPUT, "SLIM_Learn(admm): rowptr is not a non-decreasing offset array ending at nnz");
+      for (ssize_t k = rowptr[u]; k < rowptr[u + 1]; ++k) {
+        if (seen[(size_t)rowind[k]] == u)
+          return fail(SLIM_ERROR_INPUT, "SLIM_Learn(admm): duplicate (user, item) entries in the rating matrix");
+        seen[(size_t)rowind[k]] = u;
+      }
+    }
+  }
   std::printf("Learning the model using ADMM... \n");  // estimate.c:41
   std::fflush(stdout);
   const bool trace = std::getenv("SLIM_GPU_TRACE") != nullptr;

@@ -589,6 +589,61 @@ slimgpu_matrix_t* matrix_from_device(int32_t nrows, int32_t ncols, const int64_t
 
 void matrix_free(slimgpu_matrix_t* m) { destroy(m); }
 
+// A copy of a staged matrix on another device: the FINISHED views (CSR, CSC, column scalars) go
+// device to device (hipMemcpyPeerAsync: over xGMI where the devices are peers), so the target
+// neither sorts nor needs the 24 bytes per nnz of sort temporaries.  From one root the N - 1
+// copies of a node run on N - 1 different links at once.
+slimgpu_matrix_t* matrix_clone_to_device(const slimgpu_matrix_t* src, int32_t device,
+                                         int32_t* status) {
+  auto* m = new slimgpu_matrix();
+  const double t0 = now_ms();
+  try {
+    (void)hipGetLastError();
+    LearnOptions o;
+    o.device = device;
+    pick_device(m, o);
+    m->nrows = src->nrows;
+    m->ncols = src->ncols;
+    m->nnz = src->nnz;
+    m->binary = src->binary;
+    m->exact_gram = src->exact_gram;
+    m->owns_csr = true;
+    m->h_cost = src->h_cost;
+    const size_t nz = (size_t)std::max<int64_t>(m->nnz, 1);
+    m->d_rowptr = dev_alloc<int64_t>((size_t)m->nrows + 1);
+    m->d_rowind = dev_alloc<int32_t>(nz);
+    m->d_rowval = m->binary ? nullptr : dev_alloc<float>(nz);
+    m->d_colptr = dev_alloc<int64_t>((size_t)m->ncols + 1);
+    m->d_colind = dev_alloc<int32_t>(nz);
+    m->d_colval = m->binary ? nullptr : dev_alloc<float>(nz);
+    m->d_cnorm = dev_alloc<float>((size_t)m->ncols);
+    m->d_csq = dev_alloc<float>((size_t)m->ncols);
+    auto peer = [&](void* dst, const void* from, size_t bytes) {
+      if (bytes == 0 || !dst || !from) return;
+      HIP_TRY(hipMemcpyPeerAsync(dst, m->device, from, src->device, bytes, m->stream));
+    };
+    peer(m->d_rowptr, src->d_rowptr, sizeof(int64_t) * ((size_t)m->nrows + 1));
+    peer(m->d_colptr, src->d_colptr, sizeof(int64_t) * ((size_t)m->ncols + 1));
+    peer(m->d_cnorm, src->d_cnorm, sizeof(float) * (size_t)m->ncols);
+    peer(m->d_csq, src->d_csq, sizeof(float) * (size_t)m->ncols);
+    if (m->nnz > 0) {
+      peer(m->d_rowind, src->d_rowind, sizeof(int32_t) * (size_t)m->nnz);
+      peer(m->d_colind, src->d_colind, sizeof(int32_t) * (size_t)m->nnz);
+      peer(m->d_rowval, src->d_rowval, sizeof(float) * (size_t)m->nnz);
+      peer(m->d_colval, src->d_colval, sizeof(float) * (size_t)m->nnz);
+    }
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->setup_ms = now_ms() - t0;
+    if (status) *status = SLIM_OK;
+    return m;
+  } catch (const HipError& e) {
+    report(e, "SLIMGPU_MatrixFromHost (device-to-device copy of the staged matrix)");
+    if (status) *status = status_of(e);
+    destroy(m);
+    return nullptr;
+  }
+}
+
 void matrix_add_replica(slimgpu_matrix_t* m, slimgpu_matrix_t* replica) {
   m->replicas.push_back(replica);
 }

@@ -43,6 +43,9 @@ slimgpu_matrix_t* matrix_from_device(int32_t nrows, int32_t ncols,
                                      const float* d_rowval, const LearnOptions& opt,
                                      int32_t* status);
 void matrix_free(slimgpu_matrix_t* m);
+// copy of a staged matrix (all views, no re-sort) on another device, device to device
+slimgpu_matrix_t* matrix_clone_to_device(const slimgpu_matrix_t* src, int32_t device,
+                                         int32_t* status);
 int32_t matrix_info(const slimgpu_matrix_t* m, int32_t* nrows, int32_t* ncols, int64_t* nnz);
 int32_t matrix_get_column_view(const slimgpu_matrix_t* m, int64_t* colptr, int32_t* colind,
                                float* colval, float* cnorms);

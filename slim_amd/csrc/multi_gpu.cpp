@@ -10,7 +10,8 @@
 // Replication of R: every device thread copies the caller's CSR over its own PCIe link
 // (default, "h2d"), or device 0 receives it once and RCCL broadcasts it over xGMI
 // (SLIM_GPU_STAGE=rccl; librccl is loaded on demand, the library has no link-time
-// dependency on it).  Both leave every device with its own column view.
+// dependency on it); both leave every device to build its own column view.  SLIM_GPU_STAGE=view
+// stages on the first device only and copies the finished views device to device.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -37,6 +38,18 @@ bool resolve_devices(const LearnOptions& opt, std::vector<int>* out, std::string
     *err = "no usable gfx950 device -- the SLIM CD path has no CPU fallback";
     return false;
   }
+  // An explicit device option (SLIM_OPTION_GPU_DEVICE with ngpus <= 1: what a
+  // one-process-per-GPU launcher passes) wins over the environment: a rank that inherits
+  // SLIM_GPU_DEVICES must not replicate R on every listed GPU.
+  if (opt.ngpus <= 1 && opt.device >= 0) {
+    if (opt.device >= count) {
+      *err = "device " + std::to_string(opt.device) + " requested but the node has " +
+             std::to_string(count);
+      return false;
+    }
+    out->push_back(opt.device);
+    return true;
+  }
   if (const char* e = std::getenv("SLIM_GPU_DEVICES")) {
     for (const char* p = e; *p;) {
       char* end = nullptr;
@@ -50,7 +63,8 @@ bool resolve_devices(const LearnOptions& opt, std::vector<int>* out, std::string
       out->push_back((int)d);
       p = *end == ',' ? end + 1 : end;
     }
-    if ((int)out->size() > opt.ngpus && opt.ngpus > 1) out->resize((size_t)opt.ngpus);
+    // the list names the devices to use; ngpus (unset = 1) says how many of them
+    if ((int)out->size() > std::max(1, opt.ngpus)) out->resize((size_t)std::max(1, opt.ngpus));
     if (!out->empty()) return true;
   }
   if (opt.ngpus <= 1) {
@@ -205,6 +219,46 @@ slimgpu_matrix_t* multi_from_host(int32_t nrows, const ssize_t* rowptr, const in
   std::vector<slimgpu_matrix_t*> mats(n, nullptr);
   std::vector<int32_t> st(n, SLIM_ERROR);
   std::vector<std::string> msg(n);
+  // SLIM_GPU_STAGE=view: the first device stages R (one H2D copy, one sort), every other
+  // device receives the finished CSR + CSC + column scalars device to device -- N - 1 peer
+  // copies on N - 1 xGMI links at once, no sort and no sort temporaries on the targets.
+  // Which form wins on a real node (this, N parallel H2D copies + N sorts, or the RCCL
+  // broadcast of the CSR) is unmeasured: no multi-GPU box is available to the builder; all three
+  // are ~1 s against a solve of a minute.
+  if (stage && std::strcmp(stage, "view") == 0 && n > 1) {
+    LearnOptions o0 = opt;
+    o0.device = devs[0];
+    o0.ngpus = 1;
+    mats[0] = matrix_from_host(nrows, rowptr, rowind, rowval, o0, status);
+    if (!mats[0]) return nullptr;
+    auto clone = [&](size_t d) {
+      set_error("");
+      mats[d] = matrix_clone_to_device(mats[0], devs[d], &st[d]);
+      if (!mats[d]) msg[d] = last_error();
+    };
+    {
+      std::vector<std::thread> team;
+      for (size_t d = 1; d < n; ++d) team.emplace_back(clone, d);
+      for (auto& t : team) t.join();
+    }
+    double setup_ms = matrix_setup_ms(mats[0]), copy_ms = 0;
+    for (size_t d = 1; d < n; ++d) {
+      if (!mats[d]) {
+        set_error(msg[d]);
+        if (status) *status = st[d];
+        for (slimgpu_matrix_t* m : mats) matrix_free(m);
+        return nullptr;
+      }
+      copy_ms = std::max(copy_ms, matrix_setup_ms(mats[d]));
+    }
+    if (std::getenv("SLIM_GPU_TRACE"))
+      std::fprintf(stderr, "[trace] staging 'view': device %d staged in %.1f ms, %zu device-to-device "
+                           "copies in %.1f ms\n", devs[0], setup_ms, n - 1, copy_ms);
+    for (size_t d = 1; d < n; ++d) matrix_add_replica(mats[0], mats[d]);
+    matrix_set_setup_ms(mats[0], setup_ms + copy_ms);
+    if (status) *status = SLIM_OK;
+    return mats[0];
+  }
   std::vector<DevCsr> bufs;
   if (use_rccl && !broadcast_csr_rccl(devs, nrows, rowptr, rowind, rowval, &bufs, &err)) {
     set_error("SLIM_Learn: " + err);

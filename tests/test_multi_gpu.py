@@ -111,6 +111,37 @@ def test_rccl_staging_path(ml100k, monkeypatch):
     assert maxdiff(W1, W2) == 0.0
 
 
+def test_view_staging_path(ml100k, monkeypatch, capfd):
+    """SLIM_GPU_STAGE=view: one device stages R, the other receives the finished CSR + CSC +
+    column scalars device to device (no second sort); the two-shard model is the one-GPU model.
+    On a one-GPU box both replicas live on device 0 (the copy is then a D2D copy)."""
+    R, _ = ml100k
+    W1, st1, _ = _slim_learn(R, L1R=1.0, L2R=1.0)
+    assert st1 == 1
+    if _lib.load().SLIMGPU_DeviceCount() < 2:
+        monkeypatch.setenv("SLIM_GPU_DEVICES", "0,0")
+    monkeypatch.setenv("SLIM_GPU_STAGE", "view")
+    monkeypatch.setenv("SLIM_GPU_TRACE", "1")
+    W2, st2, s2 = _slim_learn(R, ngpus=2, L1R=1.0, L2R=1.0)
+    assert st2 == 1, s2
+    assert "staging 'view'" in capfd.readouterr().err
+    assert W2.nnz == W1.nnz and maxdiff(W1, W2) == 0.0
+
+
+def test_explicit_device_wins_over_the_environment(ml100k, monkeypatch):
+    """a one-process-per-GPU rank that inherits SLIM_GPU_DEVICES must not replicate R
+    on every listed device -- an explicit device option with ngpus <= 1 is honoured, and a list
+    longer than ngpus is cut to ngpus entries."""
+    R, _ = ml100k
+    monkeypatch.setenv("SLIM_GPU_DEVICES", "0,0,0")
+    m = DeviceMatrix.from_scipy(R, device=0)
+    W, st = m.learn(seed=1)
+    assert st["ncols_solved"] == R.shape[1]      # one matrix, one solve: no fan-out
+    m.close()
+    W1, st1, s1 = _slim_learn(R, L1R=1.0, L2R=1.0)    # ngpus unset: the first listed device only
+    assert st1 == 1 and s1["ncols_solved"] == R.shape[1]
+
+
 def test_mselect_grid_over_two_shards(automotive_triplets, monkeypatch, capsys):
     """Py_SLIM_Mselect keeps R on every device of the team across the grid."""
     from slim_amd.interface import SLIM, SLIMatrix
