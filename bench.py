@@ -8,8 +8,8 @@ configs[3], 1M users x 100K items, ~1e9 nnz, l1 = l2 = 1, optTol 1e-7 (the confi
 the metric is quoted on; it fits one GPU).  With N GPUs (one process per GPU) every rank
 solves shard `rank` of N of the step's columns (granules of 32 columns of the cost-ordered
 work list dealt round-robin; RCCL only for the one-off broadcast of R and the gather of the
-learned columns).  Default: B = 8960 columns per GPU and step => weak scaling (at N = 8 a
-step covers 71 680 of the 100 000 columns).  --scaling strong fixes the columns per step
+learned columns).  Default: B = 8192 columns per GPU and step => weak scaling (at N = 8 a
+step covers 65 536 of the 100 000 columns).  --scaling strong fixes the columns per step
 (--batch 0: the whole matrix, north_star's target; 555 s per step on one GPU, which is why
 it is not the default under the driver's 25-step run).
 
@@ -74,13 +74,13 @@ def parse_args():
     return ap.parse_args()
 
 
-# Columns per GPU and step.  8960 = 280 tiles of 32: with the engine's geometry at this size
-# (64 clusters of 4 workgroups after a heavy phase that costs ~30 tile-slots) that is 4.9 rounds;
-# 8192 = 256 tiles is 4.4 rounds, so most clusters idle through half of a fifth one (busy 0.90
-# against 0.94: 135 against 142 columns/s on the same box, profiles/r02/c4_batch.txt).  The
-# whole-matrix step (49 rounds, busy 0.97, 163 columns/s) is what either approximates inside
-# the driver's 25 x step time box.
-DEFAULT_BATCH = 8960
+# Columns per GPU and step: 8192 = 256 tiles of 32.  (Round 2 used 8960, the size that fills the
+# engine's rounds of 64 clusters best; a caller cannot choose that, so the default is a round
+# number again.  Measured side by side, profiles/r03/c4_batch.txt: 8192 columns take 4.59 median
+# tile times, 8960 take 4.90 -- 2.5 % apart per column; the rest of what separates two runs is
+# the box, +-8 % from run to run.)  The whole-matrix step (--scaling strong --batch 0: 49 rounds,
+# busy 0.97) is what either approximates inside the driver's 25 x step time box.
+DEFAULT_BATCH = 8192
 
 KERNEL_NAMES = {0: "auto", 1: "wave-lds", 2: "wave-hbm", 3: "tile32", 4: "tile16"}
 

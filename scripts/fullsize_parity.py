@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tiles", default="median,sampled")
     ap.add_argument("--batch-begin", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=8960)
+    ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--noise", action="store_true", help="also oracle-vs-oracle order noise")
     ap.add_argument("--tight", action="store_true", help="also optTol 1e-12 vs ORDER_PERM")

@@ -78,9 +78,9 @@ def test_c4_full_size_tiles_match_oracle_in_tile_order():
     mat, R = _stage("c4")
     O.cache_setup(True)           # one transpose of R for the oracle calls of this test
     threads = min(32, O.max_threads())
-    tiles = _batch_tiles(mat, 0, 8960)   # bench.py DEFAULT_BATCH
+    tiles = _batch_tiles(mat, 0, 8192)   # bench.py DEFAULT_BATCH
     rng = np.random.default_rng(1)
-    c0 = int(np.sort(rng.permutation(8960)[:8])[0])
+    c0 = int(np.sort(rng.permutation(8192)[:8])[0])
     sampled = int(np.where(tiles == c0)[0][0])
     picked = [tiles[len(tiles) // 2], tiles[sampled]]
     results = [_check_tile(mat, R, t, threads) for t in picked]      # one tile: clusters of 16
