@@ -1,11 +1,19 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03
-timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
-export SLIM_GPU_TRACE=1
-for rep in 1 2; do for v in nopf cur; do
-  lib=$PWD/variants/libslim_$v.so; [ $v = cur ] && lib=$PWD/slim_amd/libslim.so
-  echo "## 0.1pct default $v"; SLIM_AMD_LIB=$lib timeout 600 python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --workload c4-0.1pct 2>&1 | grep -E "trace\] tiles" | cut -c1-330
-  echo "## 0.1pct 32768 $v"; SLIM_AMD_LIB=$lib timeout 600 python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --workload c4-0.1pct --batch 32768 2>&1 | grep -E "trace\] tiles" | cut -c1-330
-  echo "## c4 default $v"; SLIM_AMD_LIB=$lib timeout 600 python bench.py --steps 1 --warmup 0 --cpu-seconds 0 2>&1 | grep -E "trace\] tiles" | cut -c1-330
-done; done > gpurun_out/r03/call12_pf.txt 2>&1
-cat gpurun_out/r03/call12_pf.txt
+timeout 2700 python -m pytest tests -x -q -m gpu > gpurun_out/r03/final_tests.txt 2>&1
+tail -2 gpurun_out/r03/final_tests.txt
+timeout 1500 bash scripts/collect_profiles.sh r03_c4 > gpurun_out/r03/collect_c4.log 2>&1
+tail -12 gpurun_out/r03/collect_c4.log | cut -c1-600
+timeout 1200 bash scripts/collect_profiles.sh r03_c5 --workload c5 --batch 4096 > gpurun_out/r03/collect_c5.log 2>&1
+tail -12 gpurun_out/r03/collect_c5.log | cut -c1-600
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03_warm_pmc_$c -o run -- python $GRAFT_REPO_ROOT/scripts/warm_ab.py --columns 4096 --variants row:1:0:1 > $GRAFT_REPO_ROOT/gpurun_out/r03/warm_pmc_$c.txt 2>&1
+done
+cd $GRAFT_REPO_ROOT
+grep -h "cd_tile" gpurun_out/r03_warm_pmc_*/run_counter_collection.csv | cut -c1-300
+grep "^{" gpurun_out/r03/warm_pmc_FETCH_SIZE.txt | cut -c1-250
+find gpurun_out -name "*kernel_trace.csv" -size +20M -delete
+timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3
+timeout 1500 python bench.py --steps 2 --warmup 1 > gpurun_out/r03/bench_default.json 2> gpurun_out/r03/bench_default.err
+tail -1 gpurun_out/r03/bench_default.json | cut -c1-3000
