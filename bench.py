@@ -400,6 +400,12 @@ def pmc_traffic(args, columns, kernel, binary, world=1):
     return None
 
 
+def rowind_col_nnz(R, col):
+    """Number of ratings of one item (column of the CSR matrix R)."""
+    import numpy as np
+    return int(np.count_nonzero(R.indices == col))
+
+
 def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts, W_gpu):
     """The CPU restatement of the reference's OpenMP CD path (oracle/slim_oracle.c:
     estimate.c:328-558 + cd.c, reference arithmetic: fp64, three passes per visit) timed on
@@ -474,6 +480,14 @@ def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts,
     diff = abs(Wg[:, sample] - Wc[:, sample])
     d_sample = float(diff.max()) if diff.nnz else 0.0
     w_max = float(abs(Wc[:, sample]).max()) if Wc[:, sample].nnz else 0.0
+    worst = {}
+    if diff.nnz:   # where the largest difference sits, and how large that column's coefficients are
+        dc = diff.tocoo()
+        k = int(dc.data.argmax())
+        col = int(sample[dc.col[k]])
+        worst = {"column": col, "row": int(dc.row[k]),
+                 "column_max_abs_W": float(abs(Wc[:, [col]]).max()),
+                 "column_nnz": int(rowind_col_nnz(R, col))}
     # two valid visiting orders stop at slightly different points at optTol 1e-7 (the reference
     # differs from itself by 0.25 % of max|W| across shuffle seeds on ml100k; 1.4e-5 of 7.5e-3 on a
     # C4 median tile, profiles/r02/fullsize_parity.txt; 1.9e-4 over 256 C4 columns that include
@@ -505,7 +519,7 @@ def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts,
         "parity": {
             "tile_order_max_abs_dW": d_tile, "tile": "tile %d of %d of the last step" % (g, ntiles),
             "tile_order_tolerance": 2e-5,
-            "sample_max_abs_dW": d_sample, "sample_max_abs_W": w_max,
+            "sample_max_abs_dW": d_sample, "sample_max_abs_W": w_max, "sample_worst": worst,
             "sample_tolerance": tol_sample,
             "parity_ok": bool((d_tile is None or d_tile <= 2e-5) and d_sample <= tol_sample),
             "note": "tile: GPU vs oracle_learn_cd_tile walking the same tile in the kernel's "

@@ -1,19 +1,11 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03
-timeout 2700 python -m pytest tests -x -q -m gpu > gpurun_out/r03/final_tests.txt 2>&1
-tail -2 gpurun_out/r03/final_tests.txt
-timeout 1500 bash scripts/collect_profiles.sh r03_c4 > gpurun_out/r03/collect_c4.log 2>&1
-tail -12 gpurun_out/r03/collect_c4.log | cut -c1-600
-timeout 1200 bash scripts/collect_profiles.sh r03_c5 --workload c5 --batch 4096 > gpurun_out/r03/collect_c5.log 2>&1
-tail -12 gpurun_out/r03/collect_c5.log | cut -c1-600
-cd /tmp && export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03_warm_pmc_$c -o run -- python $GRAFT_REPO_ROOT/scripts/warm_ab.py --columns 4096 --variants row:1:0:1 > $GRAFT_REPO_ROOT/gpurun_out/r03/warm_pmc_$c.txt 2>&1
-done
-cd $GRAFT_REPO_ROOT
-grep -h "cd_tile" gpurun_out/r03_warm_pmc_*/run_counter_collection.csv | cut -c1-300
-grep "^{" gpurun_out/r03/warm_pmc_FETCH_SIZE.txt | cut -c1-250
+timeout 1800 python bench.py --gpus 1 --steps 10 --warmup 2 > gpurun_out/r03/bench_10steps.json 2> gpurun_out/r03/bench_10steps.err
+tail -1 gpurun_out/r03/bench_10steps.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['frac_physical'], d['cpu_baseline']['value'], d['cpu_baseline']['parity'])"
+export SLIM_GPU_TRACE=1
+timeout 1200 python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --scaling strong --batch 0 > gpurun_out/r03/c4_whole_matrix.json 2> gpurun_out/r03/c4_whole_matrix.err
+grep "trace\] tiles" gpurun_out/r03/c4_whole_matrix.err | cut -c1-330; cut -c1-400 gpurun_out/r03/c4_whole_matrix.json
+unset SLIM_GPU_TRACE
+STEPS=1 timeout 1200 bash scripts/collect_profiles.sh r03_c401 --workload c4-0.1pct --scaling strong --batch 0 > gpurun_out/r03/collect_c401.log 2>&1
+tail -14 gpurun_out/r03/collect_c401.log | cut -c1-500
 find gpurun_out -name "*kernel_trace.csv" -size +20M -delete
-timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3
-timeout 1500 python bench.py --steps 2 --warmup 1 > gpurun_out/r03/bench_default.json 2> gpurun_out/r03/bench_default.err
-tail -1 gpurun_out/r03/bench_default.json | cut -c1-3000
