@@ -159,7 +159,14 @@ int32_t SLIMGPU_MatrixColumnCost(const slimgpu_matrix_t *mat, int64_t *cost);
 /* The estimate step of SLIM_Learn (EstimateModelCD + SaveModel,
  * src/libslim/estimate.c:328-593) on a staged matrix.  Same options, imodel and
  * result conventions as SLIM_Learn; can be called repeatedly on one matrix
- * (model-selection grids keep R resident). */
+ * (model-selection grids keep R resident).  A call that solves the same columns
+ * as the previous call on this matrix (the next (l1, l2) pair of a grid,
+ * src/programs/slim_mselect.c:99-113) reuses that call's screen sums a_i.y --
+ * they depend on R only -- instead of recomputing them (kept in HBM with the
+ * matrix, at most half of the free memory; SLIM_GPU_NO_GRAM=1 disables it);
+ * the model is the same bit for bit.  Input rules (checked while R is staged,
+ * SLIM_ERROR_INPUT otherwise): non-decreasing row offsets ending at nnz, item
+ * ids inside [0, ncols), no (user, item) pair twice. */
 slim_t *SLIMGPU_Learn(slimgpu_matrix_t *mat, int32_t *ioptions,
                       double *doptions, slim_t *imodel, int32_t *r_status);
 
