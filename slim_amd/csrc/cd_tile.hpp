@@ -16,25 +16,35 @@
 //   * the P problems visit coordinates in the same order, so each column of R
 //     (ids + values) is read once per tile instead of once per item, with
 //     coalesced loads: wavefront w of the workgroup owns 64 consecutive nnz of
-//     each 1024-nnz chunk of the visited column, loads their ids/values with one
-//     256-byte request each, and hands them to its lane groups through the
-//     cross-lane network (no LDS staging, no extra barrier);
-//   * a wavefront step covers 64/P users x P problems; all steps of a chunk
-//     (P loads per lane) are in flight together.  The P dot products are reduced
-//     with log2(64/P) cross-lane adds + one LDS exchange per visit; every
+//     each 1024-nnz chunk of the visited column.  The 16-lane rows of a lane group
+//     (P lanes = the P problems of one user) load the same 16 entries, and step j
+//     of group g reads entry g * P + j with one DPP row broadcast (no LDS staging,
+//     no permute, no address register per step);
+//   * a wavefront step covers 64/P users x P problems; all steps of a block
+//     (P loads per lane) are in flight together, and a slice of several chunks is one
+//     stream: two blocks alternate, the ids of chunk k+2 are requested before the
+//     gathers of chunk k+1 (loads complete in issue order), and no load of the
+//     stream is conditional -- entries past the end of a slice point at a spare
+//     line behind the member's user range that holds 0.  The P dot products are
+//     reduced with log2(64/P) cross-lane adds + one LDS exchange per visit; every
 //     wavefront then evaluates the P soft-threshold updates redundantly (bitwise
-//     identical, so control flow stays workgroup-uniform) and applies the
-//     residual update to its own nnz, storing whole lines (all P problems of a
-//     user, changed or not -- no read-modify-write in L2/HBM);
-//   * the last chunk of a column stays in registers between dot and update
-//     (store-only update); earlier chunks of long columns are re-read;
+//     identical, so control flow stays workgroup-uniform) and applies the residual
+//     update to its own nnz, storing whole lines (all P problems of a user,
+//     changed or not -- no read-modify-write in L2/HBM);
+//   * the last TWO chunks of a slice stay in registers between dot and update
+//     (store-only update); earlier chunks of longer slices are read again;
 //   * the next visit's scalars (column id, offsets, x row, norms) are loaded one
-//     visit ahead;
+//     visit ahead with scalar-base addressing; per-problem counters live in LDS;
 //   * the screen aTy > l1 (estimate.c:412-444) is one extra pass a_i . y over every
 //     column for the P problems at once, each wavefront taking whole columns and
 //     skipping the users outside the tile's user set through an LDS bitmap -- no
 //     atomics, a fixed summation order (round 1 accumulated the Gram column with
-//     device-scope float atomics: twice the time, and order-dependent sums).
+//     device-scope float atomics: twice the time, and order-dependent sums).  The
+//     sums depend on R only: they are kept in HBM and read by the next solve of the
+//     same columns (S.gram_mode; model-selection grids);
+//   * a warm start's coefficients are folded into the residual row by row (FOLD = 2:
+//     r[u] = y[u] - sum_j v_uj x_j over the member's users, x lines from ONE copy per
+//     cluster) instead of a gather + write-back per column of the union.
 //
 // Per problem the arithmetic is exactly that of cd_wave.hpp (and of the
 // reference, src/libslim/cd.c:101-142): same update rule, same epsilon rule,
