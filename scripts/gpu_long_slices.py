@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""GPU probe: slices of one to five chunks per visit (60 000 x 96 valued matrix, ~4800 nnz per
+column) through every cluster / heavy-phase geometry, with and without the heavy phase's id
+prefetch, against the oracle walking the same tiles.  Found the round-3 bug in which the values
+of a block were replaced before the block had been summed (valued matrices, >= 3 chunks)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Warm-started grid step A/B on one box (slim_mselect.c:99-113): pair 1 of
 tests/golden/l12file cold, then pair 2 from that model once per variant of the environment
-(fold:xcd:token:gram = SLIM_GPU_FOLD row | col, SLIM_GPU_XCD 1 | 0, SLIM_GPU_FOLD_TOKEN 1 | 0,
-screen-sum cache 1 | 0) -- the variants differ in nothing but how the
+(fold:xcd:gram = SLIM_GPU_FOLD row | col, SLIM_GPU_XCD 1 | 0, screen-sum cache 1 | 0; a fourth
+field, the per-XCD fold token of profiles/r03/warm_step_ab.txt, existed while that experiment did) -- the variants differ in nothing but how the
 previous coefficients are folded into the residual and where the cluster members sit.
 
   python scripts/warm_ab.py [--workload c5] [--columns 0] [--variants row:1,row:0,col:1]
@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--workload", default="c5")
     ap.add_argument("--columns", type=int, default=0)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--variants", default="row:1,row:0,col:1")
+    ap.add_argument("--variants", default="row:1:1,row:0:1,col:1:1,row:1:0")
     ap.add_argument("--cold-tol", type=float, default=1e-7)
     args = ap.parse_args()
     import torch
@@ -55,21 +55,21 @@ def main():
 
     first = solve(pairs[0][0], pairs[0][1], None, "cold")
     for v in args.variants.split(","):
-        f = (v.split(":") + ["1", "1"])[:4]
-        fold, xcd, token, gram = f
+        f = v.split(":")
+        fold, xcd = f[0], f[1]
+        gram = f[-1] if len(f) > 2 else "1"
         os.environ["SLIM_GPU_FOLD"] = fold
         os.environ["SLIM_GPU_XCD"] = xcd
-        os.environ["SLIM_GPU_FOLD_TOKEN"] = token
         if gram == "0":
             os.environ["SLIM_GPU_NO_GRAM"] = "1"
         else:
             os.environ.pop("SLIM_GPU_NO_GRAM", None)
         h = solve(pairs[1][0], pairs[1][1], first,
-                  "warm fold=%s xcd=%s token=%s gram=%s" % (fold, xcd, token, gram))
+                  "warm fold=%s xcd=%s gram=%s" % (fold, xcd, gram))
         import ctypes as C
         mat._lib.SLIM_FreeModel(C.byref(C.c_void_p(h)))
     # an l1 step from the same model (several sweeps), default settings
-    for k in ("SLIM_GPU_FOLD", "SLIM_GPU_XCD", "SLIM_GPU_FOLD_TOKEN", "SLIM_GPU_NO_GRAM"):
+    for k in ("SLIM_GPU_FOLD", "SLIM_GPU_XCD", "SLIM_GPU_NO_GRAM"):
         os.environ.pop(k, None)
     solve(pairs[9][0], pairs[9][1], first, "warm l1 step (defaults)")
 
