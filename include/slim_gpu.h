@@ -121,7 +121,11 @@ typedef enum {
   SLIMGPU_KERNEL_WAVE_HBM = 2, /* one wavefront per item, work vectors in HBM  */
   SLIMGPU_KERNEL_TILE = 3,     /* one workgroup per 32 items, residuals
                                   interleaved r[user][32] in HBM (large matrices) */
-  SLIMGPU_KERNEL_TILE16 = 4    /* same with 16 items per workgroup             */
+  SLIMGPU_KERNEL_TILE16 = 4,   /* same with 16 items per workgroup             */
+  SLIMGPU_KERNEL_GRAM = 5      /* item-space CD: one workgroup per item, g = a_i.r over the
+                                  ITEMS in LDS, updates read rows of G = R^T R (built on the
+                                  first such solve, kept with the handle; <= ~40K items).
+                                  AUTO takes it for repeated solves of one matrix         */
 } slimgpu_kernel_et;
 
 /* A training matrix staged in HBM: CSR as given + the column view (CSC, rows
@@ -151,6 +155,11 @@ int32_t SLIMGPU_MatrixInfo(const slimgpu_matrix_t *mat, int32_t *nrows,
 int32_t SLIMGPU_MatrixGetColumnView(const slimgpu_matrix_t *mat, int64_t *colptr,
                                     int32_t *colind, float *colval,
                                     float *cnorms);
+
+/* Announce that the matrix is about to be solved nsolves times (a model-selection grid,
+ * src/programs/slim_mselect.c:94-113): with nsolves >= 2 SLIMGPU_KERNEL_AUTO may build
+ * G = R^T R once and run every solve in item space (SLIMGPU_KERNEL_GRAM).  0 withdraws it. */
+void SLIMGPU_MatrixExpectSolves(slimgpu_matrix_t *mat, int32_t nsolves);
 
 /* Scheduling cost proxy per item column (the Gram work G = sum over the column's
  * users of nnz(row u)); multi-GPU drivers balance their column blocks with it. */
@@ -216,6 +225,8 @@ typedef struct slimgpu_stats_t {
   double alg_bytes;        /* 8G + 12D + 4U + 8 nnzW (4G + 8D + 4U + 8 nnzW
                               for a binary matrix): SURVEY.md 8(d)            */
   double error, objval;    /* sum of 1/2||r||^2 and of the objective          */
+  double gram_build_ms;    /* SLIMGPU_KERNEL_GRAM: time spent building G = R^T R in
+                              this call (0 when it was there already)          */
 } slimgpu_stats_t;
 int32_t SLIMGPU_LastStats(slimgpu_stats_t *out);
 

@@ -25,10 +25,14 @@ def main():
     ap.add_argument("--columns", type=int, default=0, help="solve only the first N columns (0 = all)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cluster", type=int, default=0, help="tile cluster size (0 = automatic)")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "tile", "gram"],
+                    help="auto: the engine's choice (item-space CD once the grid is announced)")
+    ap.add_argument("--no-announce", action="store_true",
+                    help="do not tell the engine how many solves are coming (SLIMGPU_MatrixExpectSolves)")
     args = ap.parse_args()
     import torch
     from slim_amd import synth
-    from slim_amd.engine import DeviceMatrix
+    from slim_amd.engine import KERNEL_AUTO, KERNEL_GRAM, KERNEL_TILE, DeviceMatrix
 
     dev = torch.device("cuda", 0)
     nrows, ncols, target = synth.scaled(args.workload, args.scale) if args.scale != 1 \
@@ -40,13 +44,16 @@ def main():
     pairs = [tuple(map(float, l.split())) for l in open(os.path.join(ROOT, "tests", "golden", "l12file"))
              if l.strip()][:args.pairs]
     ce = args.columns or mat.ncols
+    kernel = {"auto": KERNEL_AUTO, "tile": KERNEL_TILE, "gram": KERNEL_GRAM}[args.kernel]
+    if not args.no_announce:
+        mat.expect_solves(len(pairs))
     prev = None
     out = []
     t_all = time.time()
     for l1, l2 in pairs:
         t0 = time.time()
         h, st = mat.learn(imodel=prev, return_handle=True, l1r=l1, l2r=l2, optTol=1e-7, niters=10000,
-                          seed=args.seed, col_begin=0, col_end=ce,
+                          seed=args.seed, col_begin=0, col_end=ce, kernel=kernel,
                           **({"cluster": args.cluster} if args.cluster else {}))
         dt = time.time() - t0
         if prev is not None:
@@ -57,6 +64,8 @@ def main():
                "kernel_s": round(st["kernel_ms"] * 1e-3, 2), "columns_per_s": round(ce / dt, 1),
                "alg_GBps": round(st["alg_bytes"] / (st["kernel_ms"] * 1e-3) / 1e9, 1),
                "nnzW": int(st["nnzW"]), "mean_sweeps": round(float(cs.sweeps[:ce].mean()), 2),
+               "kernel": int(st["kernel"]), "gram_build_s": round(st["gram_build_ms"] * 1e-3, 2),
+               "gather_s": round(st["gather_ms"] * 1e-3, 2), "updates_per_col": round(float(cs.U[:ce].sum()) / max(float(cs.D[:ce].sum()), 1.0), 4),
                "warm": len(out) > 0}
         out.append(rec)
         print(json.dumps(rec), flush=True)

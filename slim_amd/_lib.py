@@ -27,7 +27,7 @@ class Stats(C.Structure):
                 ("gather_ms", C.c_double), ("total_ms", C.c_double),
                 ("G", C.c_int64), ("D", C.c_int64), ("U", C.c_int64), ("nnzW", C.c_int64),
                 ("sweeps", C.c_int64), ("visits", C.c_int64), ("alg_bytes", C.c_double),
-                ("error", C.c_double), ("objval", C.c_double)]
+                ("error", C.c_double), ("objval", C.c_double), ("gram_build_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -84,6 +84,7 @@ _SIGNATURES = {
                                        C.POINTER(C.c_int64)]),
     "SLIMGPU_MatrixGetColumnView": (C.c_int32, [C.c_void_p] * 5),
     "SLIMGPU_MatrixColumnCost": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "SLIMGPU_MatrixExpectSolves": (None, [C.c_void_p, C.c_int32]),
     "SLIMGPU_Learn": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_int32)]),
     "SLIMGPU_LearnColumns": (C.c_void_p, [C.c_void_p, C.c_int32, i32_1d, C.c_void_p, C.c_void_p,

@@ -294,7 +294,9 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     // Screen sums of this tile kept from an earlier solve of the same columns (a model-selection
     // grid solves every (l1, l2) pair over the same R: a_i . y does not depend on the pair):
     // S.gram_mode 2 = read them instead of running the screen pass, 1 = record them
-    float* const gram_t = S.gram_mode != 0 ? S.gram + (int64_t)grp * S.x_stride : nullptr;
+    // (3 = the sums are the product: rows item_q of G = R^T R are written and the tile is done)
+    float* const gram_t =
+        (S.gram_mode == 1 || S.gram_mode == 2) ? S.gram + (int64_t)grp * S.x_stride : nullptr;
     const bool cached = S.gram_mode == 2;
     if (tid < P) {
       s_item[tid] = tid < nprob ? S.order[base + tid] : -1;
@@ -502,6 +504,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           for (int k = 0; k < K; ++k)
             a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
           if (gram_t != nullptr && mk == 0) gram_t[idx] = a;
+          if (S.gram_mode == 3 && mk == 0 && it >= 0) S.G[(int64_t)it * S.G_ld + i] = a;
         }
         const bool act = it >= 0 && i != it && a > l1;
         x[idx] = act ? 0.0f : kInactive;
@@ -509,6 +512,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       }
     }
     __syncthreads();
+    if (S.gram_mode == 3) continue;  // (the queue pull of the next round is the cluster's sync point)
 
     // -- warm start (estimate.c:453-464): previous coefficients of active coordinates
     // (in the FSLIM branch the reference never sets its warm-start flags: a no-op there)

@@ -105,8 +105,15 @@ struct SolveArgs {
   int32_t xcd_swizzle;
   // tile kernel: screen sums a_i . y of every tile, [tile][ncols][P], kept across solves of the
   // same columns (0: unused, 1: record, 2: read instead of running the screen pass)
+  // (3: build rows of G = R^T R instead of solving: the sums a_i . y of tile item q are row
+  // item_q of G -- cd_gram.hpp)
   float* gram;
   int32_t gram_mode;
+  // item-space CD (cd_gram.hpp): G = R^T R, row-major with row stride G_ld (>= ncols_pad, the
+  // padding holds 0); ulist = [tile][ncols_pad] union lists, tile_nunion their lengths
+  float* G;
+  int64_t G_ld;
+  int32_t* tile_nunion;
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;
   int64_t* out_off;

@@ -24,6 +24,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "tile_inst.hpp"
+#include "gram_inst.hpp"
 #include "cd_wave.hpp"
 #include "engine.hpp"
 #include "host_csr.hpp"
@@ -68,6 +69,14 @@ struct slimgpu_matrix {
   Buf ws_gram;
   std::vector<int32_t> gram_order;  // work list the sums belong to (empty: none recorded)
   int gram_geom[6] = {0, 0, 0, 0, 0, 0};  // tileP, K, K_hi, nheavy, shard count, shard index
+  // G = R^T R (item-space CD, cd_gram.hpp): [ncols][G_ld] floats, built on the first solve that
+  // takes that path and kept with the handle
+  Buf ws_G, ws_nunion;
+  int64_t G_ld = 0;
+  bool G_ready = false;
+  double G_build_ms = 0;
+  int expect_solves = 0;            // announced by the caller (model-selection grids)
+  std::vector<int32_t> last_order;  // work list of the most recent solve
   Buf ws_order, ws_cnt, ws_off, ws_stat_i, ws_stat_l, ws_stat_f, ws_misc, ws_arena_i, ws_arena_v,
       ws_slab, ws_xslab, ws_ulist, ws_trace, ws_mailbox, ws_part, ws_icolptr, ws_icolind,
       ws_icolval;
@@ -116,15 +125,26 @@ T* dev_alloc(size_t n) {
   return static_cast<T*>(p);
 }
 
-// grow-only workspace buffer
+// grow-only workspace buffer.  `evict` (optional): the handle whose screen-sum cache is given
+// up when the device is out of memory -- the cache only saves a pass, nothing depends on it.
+void drop_screen_cache(slimgpu_matrix* m);
 template <class T>
-T* ws_get(slimgpu_matrix::Buf& b, size_t n) {
+T* ws_get(slimgpu_matrix::Buf& b, size_t n, slimgpu_matrix* evict = nullptr) {
   const size_t need = sizeof(T) * (n ? n : 1);
   if (b.bytes < need) {
     if (b.p) HIP_TRY(hipFree(b.p));
     b.p = nullptr;
     b.bytes = 0;
-    HIP_TRY(hipMalloc(&b.p, need));
+    hipError_t e = hipMalloc(&b.p, need);
+    if (e == hipErrorOutOfMemory && evict && evict->ws_gram.p && &b != &evict->ws_gram) {
+      (void)hipGetLastError();
+      drop_screen_cache(evict);
+      e = hipMalloc(&b.p, need);
+    }
+    if (e != hipSuccess) {
+      b.p = nullptr;
+      throw HipError{e, "hipMalloc(workspace)"};
+    }
     b.bytes = need;
   }
   return static_cast<T*>(b.p);
@@ -258,6 +278,13 @@ __global__ void k_col_split(int32_t ncols, int32_t K, const int32_t* __restrict_
     }
     csplit[t] = lo;
   }
+}
+
+void drop_screen_cache(slimgpu_matrix* m) {
+  if (m->ws_gram.p) (void)hipFree(m->ws_gram.p);
+  m->ws_gram.p = nullptr;
+  m->ws_gram.bytes = 0;
+  m->gram_order.clear();
 }
 
 int grid_for(int64_t n, int block, int cap_blocks) {
@@ -433,7 +460,7 @@ void destroy(slimgpu_matrix* m) {
        {&m->ws_order, &m->ws_cnt, &m->ws_off, &m->ws_stat_i, &m->ws_stat_l, &m->ws_stat_f,
         &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_xslab, &m->ws_ulist,
         &m->ws_trace, &m->ws_mailbox, &m->ws_part, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval,
-        &m->ws_gram})
+        &m->ws_gram, &m->ws_G, &m->ws_nunion})
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -664,6 +691,12 @@ int32_t matrix_info(const slimgpu_matrix_t* m, int32_t* nrows, int32_t* ncols, i
 
 double matrix_setup_ms(const slimgpu_matrix_t* m) { return m ? m->setup_ms : 0.0; }
 
+void matrix_expect_solves(slimgpu_matrix_t* m, int32_t n) {
+  if (!m) return;
+  m->expect_solves = n;
+  for (slimgpu_matrix* r : m->replicas) r->expect_solves = n;
+}
+
 int32_t matrix_column_cost(const slimgpu_matrix_t* m, int64_t* cost) {
   if (!m || !cost) return SLIM_ERROR_INPUT;
   std::memcpy(cost, m->h_cost.data(), sizeof(int64_t) * m->h_cost.size());
@@ -758,8 +791,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     // One solve at a time per device and process: the tile kernel sizes its grid to the whole
     // chip and its clusters need every member workgroup resident, which two concurrent
     // launches (two host threads calling SLIM_Learn on one GPU) would not guarantee.
-    static std::mutex device_lock[64];
-    std::lock_guard<std::mutex> solve_guard(device_lock[m->device & 63]);
+    // (recursive: the first item-space solve builds G through a nested call of this function)
+    static std::recursive_mutex device_lock[64];
+    std::lock_guard<std::recursive_mutex> solve_guard(device_lock[m->device & 63]);
 
     // work list: most expensive columns first (longest-processing-time order)
     std::vector<int32_t> order((size_t)nwork);
@@ -784,17 +818,75 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     const size_t vec_floats = (size_t)nrows_pad + 2 * (size_t)ncols_pad;
     const size_t lds_need = vec_floats * sizeof(float);
     int kernel = opt.kernel;
+    // Item-space CD on G = R^T R (cd_gram.hpp): when asked for, or -- left to the engine -- when
+    // this matrix is being solved repeatedly (G is there already; the caller announced a grid,
+    // SLIMGPU_MatrixExpectSolves; the very work list of the previous call comes again), the
+    // matrix is beyond the one-wavefront-per-item kernel, g fits the LDS of a CU and G the HBM.
+    int gram_nw = 0, gram_v = 0;
+    const bool gram_fits =
+        gram_geometry(ncols_pad, &gram_nw, &gram_v) && opt.nnbrs == 0 && !opt.build_G && ncols > 0;
+    const int64_t G_ld = round_up(ncols_pad, 64);
+    const size_t G_bytes = sizeof(float) * (size_t)ncols * (size_t)G_ld;
+    bool use_gram = false;
+    if (kernel == SLIMGPU_KERNEL_GRAM) {
+      if (!gram_fits) {
+        set_error(opt.nnbrs > 0 ? "SLIMGPU_Learn: the item-space kernel has no FSLIM form"
+                                : "SLIMGPU_Learn: the item-space kernel keeps one float per item in "
+                                  "LDS (at most ~40K items)");
+        return fail(SLIM_ERROR_INPUT);
+      }
+      use_gram = true;
+    } else if (kernel == SLIMGPU_KERNEL_AUTO && gram_fits && lds_need > 64 * 1024 &&
+               !std::getenv("SLIM_GPU_NO_GRAMCD")) {
+      const bool repeated = m->G_ready || m->expect_solves >= 2 ||
+                            (!m->last_order.empty() && m->last_order == order);
+      if (repeated) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        use_gram = m->G_ready || G_bytes + (size_t(8) << 30) <= free_b + m->ws_gram.bytes;
+      }
+    }
+    if (use_gram) kernel = SLIMGPU_KERNEL_GRAM;
+    if (use_gram && !m->G_ready) {
+      // G by the tile kernel's screen pass over every column (S.gram_mode 3), once per handle
+      const double tb = now_ms();
+      drop_screen_cache(m);  // (G holds the same sums for every column)
+      float* dG = ws_get<float>(m->ws_G, (size_t)ncols * (size_t)G_ld);
+      HIP_TRY(hipMemsetAsync(dG, 0, G_bytes, stream));
+      m->G_ld = G_ld;
+      LearnOptions bo = opt;
+      bo.kernel = SLIMGPU_KERNEL_TILE;
+      bo.build_G = true;
+      bo.col_begin = 0;
+      bo.col_end = -1;
+      bo.shard_count = 1;
+      bo.shard_index = 0;
+      bo.nnbrs = 0;
+      bo.cluster = 0;
+      bo.heavy_tiles = 0;
+      bo.dbglvl = 0;
+      int32_t bst = SLIM_OK;
+      slim_csr_t* none = learn_cd(m, bo, nullptr, &bst, nullptr, 0, false);
+      if (!none) return fail(bst);
+      csr_free(none);
+      m->G_ready = true;
+      m->G_build_ms = now_ms() - tb;
+      if (const char* te = std::getenv("SLIM_GPU_TRACE"); te && std::atoi(te) >= 1)
+        std::fprintf(stderr, "[trace] G = R^T R (%d x %d, %.2f GB) built in %.1f ms\n", ncols, ncols,
+                     G_bytes * 1e-9, m->G_build_ms);
+    }
     if (kernel == SLIMGPU_KERNEL_AUTO)
       kernel = lds_need <= 64 * 1024 ? SLIMGPU_KERNEL_WAVE_LDS : SLIMGPU_KERNEL_TILE;
     if (kernel == SLIMGPU_KERNEL_WAVE_LDS && lds_need > 160 * 1024) {
       set_error("SLIMGPU_Learn: work vectors do not fit the 160 KiB LDS of a CU");
       return fail(SLIM_ERROR_INPUT);
     }
-    if (kernel < SLIMGPU_KERNEL_WAVE_LDS || kernel > SLIMGPU_KERNEL_TILE16) {
+    if (kernel < SLIMGPU_KERNEL_WAVE_LDS || kernel > SLIMGPU_KERNEL_GRAM) {
       set_error("SLIMGPU_Learn: unknown kernel selection");
       return fail(SLIM_ERROR_INPUT);
     }
     const bool use_lds = kernel == SLIMGPU_KERNEL_WAVE_LDS;
+    const size_t gram_lds = sizeof(float) * (size_t)ncols_pad;
     // tile width: 32 item columns per workgroup (128-byte residual lines) unless the row
     // offsets would overflow the kernel's 32-bit byte offsets
     int tileP = kernel == SLIMGPU_KERNEL_TILE16 ? 16 : 32;
@@ -809,9 +901,13 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       kernel = SLIMGPU_KERNEL_WAVE_HBM;
     }
     if (use_tile) kernel = tileP == 32 ? SLIMGPU_KERNEL_TILE : SLIMGPU_KERNEL_TILE16;
+    if (opt.build_G && !use_tile) {
+      set_error("SLIMGPU_Learn: G = R^T R is built by the tile kernel, which this matrix cannot use");
+      return fail(SLIM_ERROR_INPUT);
+    }
     const char* trace_env = std::getenv("SLIM_GPU_TRACE");
     const int trace_level = trace_env ? std::atoi(trace_env) : 0;
-    KernelFn fn = pick_kernel(use_lds, !m->binary);
+    KernelFn fn = use_gram ? gram_kernel(gram_nw, gram_v) : pick_kernel(use_lds, !m->binary);
     // tile workgroup geometry: 16 wavefronts (1 workgroup per CU) or 8 (2 per CU, phases of
     // the two overlap).  SLIM_GPU_TILE_NW overrides the default.
     // Measured on C4 (profiles/r01): with few tiles per cluster the launch is bound by the
@@ -842,7 +938,18 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         fn = tileNW == 16 ? tile_kernel_p16_nw16(val, prof) : tile_kernel_p16_nw8(val, prof);
     }
     int waves_per_cu;
-    if (use_lds) {
+    if (use_gram) {  // one workgroup per problem, as many per CU as g (LDS) and registers allow
+      int per_cu = 0;
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds));
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn),
+                                                           64 * gram_nw, gram_lds));
+      if (per_cu < 1) {
+        set_error("SLIMGPU_Learn: the item-space kernel does not fit a compute unit of this device");
+        return fail(SLIM_ERROR);
+      }
+      waves_per_cu = per_cu;
+    } else if (use_lds) {
       waves_per_cu = (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_need, 1));
       if (waves_per_cu < 1) waves_per_cu = 1;
       if (lds_need > 64 * 1024)
@@ -997,7 +1104,13 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       // re-plans without clusters: the launch size must follow it)
       tile_lds = sizeof(uint32_t) * (size_t)bm_words;
     };
-    if (use_tile) {
+    int32_t* d_nunion = nullptr;
+    if (use_gram) {
+      const size_t ngroups0 = ((size_t)nwork + 31) / 32;
+      d_xslab = ws_get<float>(m->ws_xslab, (size_t)ncols_pad * (size_t)nwaves, m);
+      d_ulist = ws_get<int32_t>(m->ws_ulist, (size_t)ncols_pad * ngroups0, m);
+      d_nunion = ws_get<int32_t>(m->ws_nunion, ngroups0, m);
+    } else if (use_tile) {
       alloc_tiles();
     } else if (!use_lds) {
       d_slab = ws_get<float>(m->ws_slab, vec_floats * (size_t)nwaves);
@@ -1081,7 +1194,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     float* d_gram = nullptr;
     const int gram_geom_now[6] = {tileP, clusterK, nheavy > 0 ? clusterHi : 0, nheavy,
                                   opt.shard_count, opt.shard_index};
-    if (use_tile && !std::getenv("SLIM_GPU_NO_GRAM")) {
+    if (use_tile && !opt.build_G && !std::getenv("SLIM_GPU_NO_GRAM")) {
       const size_t ngroups0 = ((size_t)nwork + tileP - 1) / tileP;
       const size_t need = ngroups0 * tile_x * sizeof(float);
       if (!m->gram_order.empty() && m->gram_order == order && m->ws_gram.bytes >= need &&
@@ -1156,6 +1269,15 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       // the fallback another geometry)
       S.gram_mode = (attempt == 0 && !cluster_fallback) ? gram_mode : 0;
       S.gram = d_gram;
+      S.G = static_cast<float*>(m->ws_G.p);
+      S.G_ld = m->G_ld;
+      S.tile_nunion = d_nunion;
+      if (opt.build_G) S.gram_mode = 3;
+      if (use_gram) {
+        S.x_stride = (int64_t)ncols_pad;
+        S.u_stride = (int64_t)ncols_pad;
+        S.ngroups = (npend + 31) / 32;
+      }
       if (const char* e = std::getenv("SLIM_GPU_HI_PREFETCH")) S.hi_prefetch = std::atoi(e);
       if (use_tile)
         HIP_TRY(hipMemsetAsync(d_mailbox, 0, sizeof(unsigned long long) * mailbox_words, stream));
@@ -1185,6 +1307,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       const int launch_waves =
           use_tile ? std::max(1, std::min((npend + tileP - 1) / tileP, nclusters)) * clusterK
                    : std::max(1, std::min(npend, nwaves));
+      if (use_gram)  // the union of the active sets of every tile, read off G
+        hipLaunchKernelGGL(gram_union_fn(), dim3(S.ngroups), dim3(64), 0, stream, A, S);
       // the heavy phase needs at least one whole big cluster in the launch
       if (S.nheavy > 0 && launch_waves < clusterHi) S.nheavy = 0;
       // test hook: launch the last cluster one member short, which is what a CU mask or a
@@ -1203,8 +1327,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         if (const char* e = std::getenv("SLIM_GPU_XCD")) S.xcd_swizzle = std::atoi(e) != 0;
       }
       HIP_TRY(hipEventRecord(ev0, stream));
-      hipLaunchKernelGGL(fn, dim3(launch_now), dim3(use_tile ? 64 * tileNW : 64),
-                         use_lds ? lds_need : (use_tile ? tile_lds : 0), stream, A, S);
+      hipLaunchKernelGGL(fn, dim3(launch_now),
+                         dim3(use_gram ? 64 * gram_nw : (use_tile ? 64 * tileNW : 64)),
+                         use_gram ? gram_lds : (use_lds ? lds_need : (use_tile ? tile_lds : 0)),
+                         stream, A, S);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(ev1, stream));
 
@@ -1342,7 +1468,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     HIP_TRY(hipMemcpy(cs.sweeps.data(), d_sti + ncols, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cs.conv.data(), d_sti + 2 * (size_t)ncols, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cs.G.data(), d_stl, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
-    if (use_tile)  // the Gram work of a column is the staging pass's cost figure
+    if (use_tile || use_gram)  // the Gram work of a column is the staging pass's cost figure
       for (int32_t c : requested) cs.G[(size_t)c] = m->h_cost[(size_t)c];
     HIP_TRY(hipMemcpy(cs.D.data(), d_stl + ncols, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cs.U.data(), d_stl + 2 * (size_t)ncols, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
@@ -1447,6 +1573,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
                        ? 4.0 * st.G + 8.0 * st.D + 4.0 * st.U + 8.0 * st.nnzW
                        : 8.0 * st.G + 12.0 * st.D + 4.0 * st.U + 8.0 * st.nnzW;
     st.gather_ms = now_ms() - t_kernel_done;
+    st.gram_build_ms = use_gram ? m->G_build_ms : 0.0;
+    if (use_gram) m->G_build_ms = 0.0;  // (charged to the solve that paid for it)
+    if (!opt.build_G) m->last_order = requested;
     st.total_ms = now_ms() - t_begin;
     g_stats = st;
     if (opt.dbglvl & SLIM_DBG_INFO)  // estimate.c:552-555

@@ -22,6 +22,7 @@ struct LearnOptions {
   int32_t heavy_cluster = 0;  // size of those clusters (0 = auto)
   int32_t ngpus = 1;          // SLIM_Learn & co: devices to shard over (multi_gpu.cpp)
   int32_t shard_count = 1, shard_index = 0;  // one shard of the cost-ordered work list
+  bool build_G = false;  // internal: this call fills G = R^T R (engine.hip), it solves nothing
 };
 LearnOptions decode_options(const int32_t* ioptions, const double* doptions);
 
@@ -51,6 +52,9 @@ int32_t matrix_get_column_view(const slimgpu_matrix_t* m, int64_t* colptr, int32
                                float* colval, float* cnorms);
 double matrix_setup_ms(const slimgpu_matrix_t* m);
 int32_t matrix_column_cost(const slimgpu_matrix_t* m, int64_t* cost);
+// the caller is about to solve this matrix n times (a model-selection grid): lets the engine pay
+// for G = R^T R up front (item-space CD, cd_gram.hpp)
+void matrix_expect_solves(slimgpu_matrix_t* m, int32_t n);
 
 // EstimateModelCD + SaveModel on the device matrix.  Returns a host model
 // (slim_csr_t with both views) or nullptr with *status set.

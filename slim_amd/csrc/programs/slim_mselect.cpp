@@ -54,6 +54,14 @@ int main(int argc, char** argv) {
 
   FILE* lf = std::fopen(a.pos[2].c_str(), "r");
   char line[256];
+  {  // one R, as many solves as the file has pairs: let the engine plan for that
+    int32_t npairs = 0;
+    double l1, l2;
+    while (std::fgets(line, sizeof line, lf))
+      if (std::sscanf(line, "%lf %lf", &l1, &l2) == 2) ++npairs;
+    std::rewind(lf);
+    SLIMGPU_MatrixExpectSolves(R, npairs);
+  }
   slim_t* model = nullptr;
   double best_hr = 0, best_ar = 0, bh_l1 = 0, bh_l2 = 0, ba_l1 = 0, ba_l2 = 0;
   while (std::fgets(line, sizeof line, lf)) {

@@ -199,6 +199,8 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
   slimgpu_matrix_t* mat =
       admm ? nullptr : multi_from_host(trn->nrows, trn->rowptr, trn->rowind, trn->rowval, base, &status);
   if (!mat && !admm) return status;
+  // a grid of nl1 x nl2 solves over one R: the engine may pay for G = R^T R once (cd_gram.hpp)
+  if (mat) matrix_expect_solves(mat, nl1 * nl2);
 
   const int32_t trn_ncols = max_index_plus_one(trn->rowptr[trn->nrows], trn->rowind);
   const int32_t tst_ncols = max_index_plus_one(tst->rowptr[tst->nrows], tst->rowind);
@@ -400,6 +402,10 @@ int32_t SLIMGPU_MatrixGetColumnView(const slimgpu_matrix_t* mat, int64_t* colptr
 
 int32_t SLIMGPU_MatrixColumnCost(const slimgpu_matrix_t* mat, int64_t* cost) {
   return matrix_column_cost(mat, cost);
+}
+
+void SLIMGPU_MatrixExpectSolves(slimgpu_matrix_t* mat, int32_t nsolves) {
+  matrix_expect_solves(mat, nsolves);
 }
 
 slim_t* SLIMGPU_Learn(slimgpu_matrix_t* mat, int32_t* ioptions, double* doptions, slim_t* imodel,

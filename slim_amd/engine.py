@@ -13,7 +13,7 @@ import scipy.sparse as sp
 from . import _lib
 from .constants import SLIM_NOPTIONS, SLIM_OK, Opt
 
-KERNEL_AUTO, KERNEL_WAVE_LDS, KERNEL_WAVE_HBM, KERNEL_TILE, KERNEL_TILE16 = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_WAVE_LDS, KERNEL_WAVE_HBM, KERNEL_TILE, KERNEL_TILE16, KERNEL_GRAM = 0, 1, 2, 3, 4, 5
 
 
 def make_options(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=1, col_begin=None,
@@ -183,6 +183,11 @@ class DeviceMatrix(object):
 
     def column_stats(self):
         return ColumnStats(self._lib, self.ncols)
+
+    def expect_solves(self, n):
+        """Announce n solves of this matrix (a grid): KERNEL_AUTO may then build G = R^T R once
+        and solve in item space (SLIMGPU_MatrixExpectSolves)."""
+        self._lib.SLIMGPU_MatrixExpectSolves(self.handle, int(n))
 
 
 def _scipy_to_model_handle(lib, W):
