@@ -82,7 +82,7 @@ def parse_args():
 # busy 0.97) is what either approximates inside the driver's 25 x step time box.
 DEFAULT_BATCH = 8192
 
-KERNEL_NAMES = {0: "auto", 1: "wave-lds", 2: "wave-hbm", 3: "tile32", 4: "tile16"}
+KERNEL_NAMES = {0: "auto", 1: "wave-lds", 2: "wave-hbm", 3: "tile32", 4: "tile16", 5: "gram"}
 
 
 def main():

@@ -863,7 +863,9 @@ int32_t oracle_learn_cd_tile_warm(int32_t nrows, const int64_t *rowptr,
         if (imodel_colptr && iC < imodel_ncols && cfg->nnbrs <= 0) {
           for (int64_t j = imodel_colptr[iC]; j < imodel_colptr[iC + 1]; j++) {
             const int32_t k = imodel_colind[j];
-            if (k < ncols && am[k]) x[k] = imodel_colval[j];
+            /* (a negative previous value ends up 0: estimate.c:456-457 copies it, the
+             * flag-clearing loop :461-464 then resets every x < 0) */
+            if (k < ncols && am[k]) x[k] = imodel_colval[j] < 0.f ? 0.0 : imodel_colval[j];
           }
           for (int32_t k = 0; k < nu; k++) /* cd.c:108-110 */
             if (am[uni[k]]) add_spvec(&A, uni[k], x[uni[k]], yhat);

@@ -61,6 +61,11 @@ def check(name, R, oracle=True, binary=False, **kw):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        check("20000x45000 binary (g in HBM, nw16)", rnd(20000, 45000, 0.002, 8, binary=True), oracle=False, binary=True, seed=2)
+        os.environ["SLIM_GPU_GRAM_NW"] = "8"
+        check("20000x45000 binary (g in HBM, nw8)", rnd(20000, 45000, 0.002, 8, binary=True), oracle=False, binary=True, seed=2)
+        return
     R = read_csr_text(os.path.join(ROOT, "tests", "golden", "ml100k-train.csr"))
     check("ml100k (nw4 v2)", R, seed=1)
     check("60000x96 ratings (nw4)", rnd(60000, 96, 0.08, 11), seed=3)

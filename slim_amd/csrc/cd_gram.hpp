@@ -73,10 +73,16 @@ __global__ __launch_bounds__(64) void gram_union_kernel(const DevMatrix A, const
 }
 
 // NW wavefronts per workgroup, V float4 of a row per thread (4 V 64 NW >= ncols_pad).
+// V = 0: more items than the LDS holds (> ~40K) -- g lives in a per-workgroup slab in HBM (it is
+// read and rewritten on every update: 12 ncols bytes per update instead of 4, most of it served
+// by the Infinity Cache), every thread walks its float4 slices in a loop.
 template <int NW, int V>
 __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, const SolveArgs S) {
   constexpr int NT = 64 * NW;
-  extern __shared__ __attribute__((aligned(16))) float g[];  // [ncols_pad]: g_i = a_i . r
+  constexpr bool LDSG = V > 0;
+  constexpr int VV = LDSG ? V : 1;  // (array bounds of the LDS form)
+  extern __shared__ __attribute__((aligned(16))) float g_lds[];  // [ncols_pad]: g_i = a_i . r
+  float* const g = LDSG ? g_lds : S.slab + (int64_t)blockIdx.x * S.slab_stride;
   __shared__ int s_p, s_na;
   __shared__ unsigned long long s_D, s_U;
   __shared__ double s_red[2][NW];
@@ -117,8 +123,9 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
     {
       const float4* __restrict__ a4 = reinterpret_cast<const float4*>(arow);
       int na = 0;
+      const int nslice = LDSG ? V : (n4 + NT - 1) / NT;
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
+      for (int j = 0; j < nslice; ++j) {
         const int c = tid + j * NT;
         if (c < n4) {
           const float4 a = a4[c];
@@ -156,57 +163,100 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
         }
       }
       __syncthreads();
-      constexpr int FU = V <= 2 ? 4 : (V <= 5 ? 2 : 1);
-      float4 acc[V];
-#pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const int c = tid + j * NT;
-        acc[j] = c < n4 ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      for (int64_t e0 = ws; e0 < we; e0 += FU) {
-        float xv[FU];
-        const float4* rp[FU];
-#pragma unroll
-        for (int f = 0; f < FU; ++f) {
-          // entries that fold nothing (past the column, outside the active set, below the
-          // epsilon of cd.c:27) read row iC with a zero coefficient: no branch in the stream
-          int k = item;
-          float v = 0.0f;
-          if (e0 + f < we) {
-            const int kk = uni(S.icolind[e0 + f]);
-            if (kk < ncols) {
-              const float xk = uni(x[kk]);
-              if (xk > kEps) {
-                k = kk;
-                v = xk;
-              }
+      constexpr int FU = !LDSG ? 4 : (V <= 2 ? 4 : (V <= 5 ? 2 : 1));
+      // which row and coefficient entry e folds: entries that fold nothing (past the column,
+      // outside the active set, below the epsilon of cd.c:27) read row iC with a zero
+      // coefficient -- no branch in the stream of row loads
+      auto entry = [&](const int64_t e, float& v, const float4*& rp) {
+        int k = item;
+        v = 0.0f;
+        if (e < we) {
+          const int kk = uni(S.icolind[e]);
+          if (kk < ncols) {
+            const float xk = uni(x[kk]);
+            if (xk > kEps) {
+              k = kk;
+              v = xk;
             }
           }
-          xv[f] = v;
-          rp[f] = reinterpret_cast<const float4*>(Gm + (int64_t)k * ld);
         }
-        float4 rv[FU][V];
+        rp = reinterpret_cast<const float4*>(Gm + (int64_t)k * ld);
+      };
+      if (LDSG) {
+        float4 acc[VV];
 #pragma unroll
-        for (int f = 0; f < FU; ++f)
+        for (int j = 0; j < VV; ++j) {
+          const int c = tid + j * NT;
+          acc[j] = c < n4 ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int64_t e0 = ws; e0 < we; e0 += FU) {
+          float xv[FU];
+          const float4* rp[FU];
 #pragma unroll
-          for (int j = 0; j < V; ++j) {
-            const int c = tid + j * NT;
-            rv[f][j] = c < n4 ? rp[f][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int f = 0; f < FU; ++f) entry(e0 + f, xv[f], rp[f]);
+          float4 rv[FU][VV];
+#pragma unroll
+          for (int f = 0; f < FU; ++f)
+#pragma unroll
+            for (int j = 0; j < VV; ++j) {
+              const int c = tid + j * NT;
+              rv[f][j] = c < n4 ? rp[f][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+          for (int f = 0; f < FU; ++f)
+#pragma unroll
+            for (int j = 0; j < VV; ++j) {
+              acc[j].x = fmaf(-xv[f], rv[f][j].x, acc[j].x);
+              acc[j].y = fmaf(-xv[f], rv[f][j].y, acc[j].y);
+              acc[j].z = fmaf(-xv[f], rv[f][j].z, acc[j].z);
+              acc[j].w = fmaf(-xv[f], rv[f][j].w, acc[j].w);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VV; ++j) {
+          const int c = tid + j * NT;
+          if (c < n4) g4[c] = acc[j];
+        }
+      } else {
+        // g in HBM: one pass over the entries per 4 slices of g, which stay in registers for the
+        // pass -- every row is read once in all (in pieces), g is read and written once
+        constexpr int CS = 4;
+        for (int c0 = tid; c0 < n4; c0 += CS * NT) {
+          float4 acc[CS];
+#pragma unroll
+          for (int j = 0; j < CS; ++j) {
+            const int c = c0 + j * NT;
+            acc[j] = c < n4 ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          for (int64_t e0 = ws; e0 < we; e0 += FU) {
+            float xv[FU];
+            const float4* rp[FU];
+#pragma unroll
+            for (int f = 0; f < FU; ++f) entry(e0 + f, xv[f], rp[f]);
+            float4 rv[FU][CS];
+#pragma unroll
+            for (int f = 0; f < FU; ++f)
+#pragma unroll
+              for (int j = 0; j < CS; ++j) {
+                const int c = c0 + j * NT;
+                rv[f][j] = c < n4 ? rp[f][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+              }
+#pragma unroll
+            for (int f = 0; f < FU; ++f)
+#pragma unroll
+              for (int j = 0; j < CS; ++j) {
+                acc[j].x = fmaf(-xv[f], rv[f][j].x, acc[j].x);
+                acc[j].y = fmaf(-xv[f], rv[f][j].y, acc[j].y);
+                acc[j].z = fmaf(-xv[f], rv[f][j].z, acc[j].z);
+                acc[j].w = fmaf(-xv[f], rv[f][j].w, acc[j].w);
+              }
           }
 #pragma unroll
-        for (int f = 0; f < FU; ++f)
-#pragma unroll
-          for (int j = 0; j < V; ++j) {
-            acc[j].x = fmaf(-xv[f], rv[f][j].x, acc[j].x);
-            acc[j].y = fmaf(-xv[f], rv[f][j].y, acc[j].y);
-            acc[j].z = fmaf(-xv[f], rv[f][j].z, acc[j].z);
-            acc[j].w = fmaf(-xv[f], rv[f][j].w, acc[j].w);
+          for (int j = 0; j < CS; ++j) {
+            const int c = c0 + j * NT;
+            if (c < n4) g4[c] = acc[j];
           }
-      }
-#pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const int c = tid + j * NT;
-        if (c < n4) g4[c] = acc[j];
+        }
       }
     }
 
@@ -265,25 +315,51 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
             if (lane == f) Uq += (unsigned long long)len;
             const float* __restrict__ row = Gm + (int64_t)i_f * ld;
             const float4* __restrict__ r4 = reinterpret_cast<const float4*>(row);
-            float4 rv[V];
-#pragma unroll
-            for (int j = 0; j < V; ++j) {
-              const int c = tid + j * NT;
-              rv[j] = c < n4 ? r4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
             const float gsel = row[i];  // the element of the row this lane's visit needs
-            gi = fmaf(-d_f, gsel, gi);
+            if (LDSG) {
+              float4 rv[VV];
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-              const int c = tid + j * NT;
-              if (c < n4) {
-                float4 gv = g4[c];
-                gv.x = fmaf(-d_f, rv[j].x, gv.x);
-                gv.y = fmaf(-d_f, rv[j].y, gv.y);
-                gv.z = fmaf(-d_f, rv[j].z, gv.z);
-                gv.w = fmaf(-d_f, rv[j].w, gv.w);
-                g4[c] = gv;
+              for (int j = 0; j < VV; ++j) {
+                const int c = tid + j * NT;
+                rv[j] = c < n4 ? r4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
               }
+              gi = fmaf(-d_f, gsel, gi);
+#pragma unroll
+              for (int j = 0; j < VV; ++j) {
+                const int c = tid + j * NT;
+                if (c < n4) {
+                  float4 gv = g4[c];
+                  gv.x = fmaf(-d_f, rv[j].x, gv.x);
+                  gv.y = fmaf(-d_f, rv[j].y, gv.y);
+                  gv.z = fmaf(-d_f, rv[j].z, gv.z);
+                  gv.w = fmaf(-d_f, rv[j].w, gv.w);
+                  g4[c] = gv;
+                }
+              }
+            } else {
+              constexpr int CS = 4;
+              for (int c0 = tid; c0 < n4; c0 += CS * NT) {
+                float4 rv[CS], gv[CS];
+#pragma unroll
+                for (int j = 0; j < CS; ++j) {
+                  const int c = c0 + j * NT;
+                  const int cc = c < n4 ? c : c0;  // (clamped: no load under a condition)
+                  rv[j] = r4[cc];
+                  gv[j] = g4[cc];
+                }
+#pragma unroll
+                for (int j = 0; j < CS; ++j) {
+                  const int c = c0 + j * NT;
+                  if (c < n4) {
+                    gv[j].x = fmaf(-d_f, rv[j].x, gv[j].x);
+                    gv[j].y = fmaf(-d_f, rv[j].y, gv[j].y);
+                    gv[j].z = fmaf(-d_f, rv[j].z, gv[j].z);
+                    gv[j].w = fmaf(-d_f, rv[j].w, gv[j].w);
+                    g4[c] = gv[j];
+                  }
+                }
+              }
+              gi = fmaf(-d_f, gsel, gi);
             }
           }
         }

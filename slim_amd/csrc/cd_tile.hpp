@@ -528,7 +528,8 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
             const int k = S.icolind[e];
             if (k < ncols) {
               const int64_t a = (int64_t)k * P + pq;
-              if (tile_active(x[a])) x[a] = S.icolval[e];
+              // (estimate.c:456-464: a negative previous value is copied, then reset to 0)
+              if (tile_active(x[a])) x[a] = fmaxf(S.icolval[e], 0.0f);
             }
           }
         }

@@ -364,7 +364,8 @@ __global__ __launch_bounds__(64) void cd_wave_kernel(const DevMatrix A, const So
           const int mid = (lo + hi) >> 1;
           if (ids[mid] < k) lo = mid + 1; else hi = mid;
         }
-        if (lo < na && ids[lo] == k) x[lo] = S.icolval[e];
+        // (estimate.c:456-464: a negative previous value is copied and then reset to 0)
+        if (lo < na && ids[lo] == k) x[lo] = fmaxf(S.icolval[e], 0.0f);
       }
       wave_sync<USE_LDS>();
       for (int q = 0; q < na; ++q) {  // cd.c:108-110

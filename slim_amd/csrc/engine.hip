@@ -830,10 +830,14 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     bool use_gram = false;
     if (kernel == SLIMGPU_KERNEL_GRAM) {
       if (!gram_fits) {
-        set_error(opt.nnbrs > 0 ? "SLIMGPU_Learn: the item-space kernel has no FSLIM form"
-                                : "SLIMGPU_Learn: the item-space kernel keeps one float per item in "
-                                  "LDS (at most ~40K items)");
+        set_error("SLIMGPU_Learn: the item-space kernel has no FSLIM form");
         return fail(SLIM_ERROR_INPUT);
+      }
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+      if (!m->G_ready && G_bytes + (size_t(4) << 30) > free_b + m->ws_gram.bytes) {
+        set_error("SLIMGPU_Learn: G = R^T R (4 ncols^2 bytes) does not fit the free HBM");
+        return fail(SLIM_ERROR_MEMORY);
       }
       use_gram = true;
     } else if (kernel == SLIMGPU_KERNEL_AUTO && gram_fits && lds_need > 64 * 1024 &&
@@ -886,7 +890,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       return fail(SLIM_ERROR_INPUT);
     }
     const bool use_lds = kernel == SLIMGPU_KERNEL_WAVE_LDS;
-    const size_t gram_lds = sizeof(float) * (size_t)ncols_pad;
+    if (use_gram && gram_v == 0)  // g in HBM: 8 or 16 wavefronts per workgroup
+      if (const char* e = std::getenv("SLIM_GPU_GRAM_NW")) gram_nw = std::atoi(e) == 8 ? 8 : 16;
+    const size_t gram_lds = gram_v > 0 ? sizeof(float) * (size_t)ncols_pad : 0;
     // tile width: 32 item columns per workgroup (128-byte residual lines) unless the row
     // offsets would overflow the kernel's 32-bit byte offsets
     int tileP = kernel == SLIMGPU_KERNEL_TILE16 ? 16 : 32;
@@ -1108,6 +1114,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     if (use_gram) {
       const size_t ngroups0 = ((size_t)nwork + 31) / 32;
       d_xslab = ws_get<float>(m->ws_xslab, (size_t)ncols_pad * (size_t)nwaves, m);
+      if (gram_v == 0) d_slab = ws_get<float>(m->ws_slab, (size_t)ncols_pad * (size_t)nwaves, m);
       d_ulist = ws_get<int32_t>(m->ws_ulist, (size_t)ncols_pad * ngroups0, m);
       d_nunion = ws_get<int32_t>(m->ws_nunion, ngroups0, m);
     } else if (use_tile) {
@@ -1274,6 +1281,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.tile_nunion = d_nunion;
       if (opt.build_G) S.gram_mode = 3;
       if (use_gram) {
+        S.slab_stride = (int64_t)ncols_pad;
         S.x_stride = (int64_t)ncols_pad;
         S.u_stride = (int64_t)ncols_pad;
         S.ngroups = (npend + 31) / 32;

@@ -3,8 +3,12 @@
 #include "gram_inst.hpp"
 namespace slimamd {
 bool gram_geometry(int ncols_pad, int* nw, int* v) {
-  if (ncols_pad > kGramMaxColsPad) return false;
   const int n4 = ncols_pad / 4;
+  if (ncols_pad > kGramMaxColsPad) {  // g in HBM (cd_gram.hpp, V = 0)
+    *nw = 16;
+    *v = 0;
+    return true;
+  }
   if (n4 <= 2 * 256) { *nw = 4; *v = 2; }
   else if (n4 <= 2 * 512) { *nw = 8; *v = 2; }
   else if (n4 <= 2 * 1024) { *nw = 16; *v = 2; }
@@ -18,6 +22,8 @@ KernelFn gram_kernel(int nw, int v) {
   if (nw == 16 && v == 2) return cd_gram_kernel<16, 2>;
   if (nw == 16 && v == 5) return cd_gram_kernel<16, 5>;
   if (nw == 16 && v == 10) return cd_gram_kernel<16, 10>;
+  if (nw == 16 && v == 0) return cd_gram_kernel<16, 0>;
+  if (nw == 8 && v == 0) return cd_gram_kernel<8, 0>;
   return nullptr;
 }
 KernelFn gram_union_fn() { return gram_union_kernel; }

@@ -6,7 +6,8 @@
 namespace slimamd {
 
 // workgroup geometry for a matrix of ncols_pad item columns: nw wavefronts, v float4 of a row of
-// G per thread (4 * v * 64 * nw >= ncols_pad); false when g does not fit the LDS of a CU
+// G per thread (4 * v * 64 * nw >= ncols_pad), g in LDS; v = 0 when g does not fit the LDS of a
+// CU and lives in HBM instead
 bool gram_geometry(int ncols_pad, int* nw, int* v);
 KernelFn gram_kernel(int nw, int v);
 KernelFn gram_union_fn();

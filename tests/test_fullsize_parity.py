@@ -15,7 +15,7 @@ import pytest
 import scipy.sparse as sp
 
 import slim_oracle as O
-from slim_amd.engine import DeviceMatrix
+from slim_amd.engine import KERNEL_GRAM, KERNEL_TILE, DeviceMatrix
 
 pytestmark = pytest.mark.gpu
 
@@ -120,7 +120,10 @@ def test_c5_full_size_warm_started_grid_steps_match_oracle():
     chunks long, clusters of 16.  Pair 1 cold, pair 2 (an l2 step: one sweep) and an l1 step
     (the active sets shrink, several sweeps) warm-started, GPU and oracle each from their own
     previous model, in the tile's visiting order: <= 2e-5, identical active sets and sweep
-    counts.  Both forms of the fold (row-wise: the default; column-wise) are checked."""
+    counts.  Both forms of the fold (row-wise: the default; column-wise) are checked -- and the
+    same three steps in item space (KERNEL_GRAM: G = R^T R of the whole 10M x 20K matrix built
+    once, the tile's 32 problems solved on it, each step from that path's own previous model),
+    which is the path a 45-pair grid takes."""
     import os
     mat, R = _stage("c5")
     threads = min(32, O.max_threads())
@@ -130,10 +133,10 @@ def test_c5_full_size_warm_started_grid_steps_match_oracle():
              open(os.path.join(os.path.dirname(__file__), "golden", "l12file")) if ln.strip()]
     assert pairs[0] == (0.1, 0.1) and pairs[1] == (0.1, 0.5) and pairs[9] == (0.5, 0.1)
     O.cache_setup(True)
-    prev_g = prev_o = None
+    prev_g = prev_o = prev_i = None
     for step, (l1, l2) in enumerate((pairs[0], pairs[1], pairs[9])):
         kw = dict(l1r=l1, l2r=l2, optTol=1e-7)
-        W, st = mat.learn(columns=tile, niters=10000, seed=1, imodel=prev_g, **kw)
+        W, st = mat.learn(columns=tile, niters=10000, seed=1, imodel=prev_g, kernel=KERNEL_TILE, **kw)
         cs = mat.column_stats()
         sweeps_g, na_g = cs.sweeps[tile].copy(), cs.nacols[tile].copy()
         Wo, so, _, _ = O.learn_cd_tile(R, tileP=32, order=tile, maxniters=10000, seed=1,
@@ -143,11 +146,21 @@ def test_c5_full_size_warm_started_grid_steps_match_oracle():
         assert np.array_equal(na_g, so["nacols"][tile])
         assert (sweeps_g == so["sweeps"][tile]).mean() >= 0.98
         assert maxdiff(W[:, tile], Wo[:, tile]) <= 2e-5
+        # the same step in item space
+        Wi, si = mat.learn(columns=tile, niters=10000, seed=1, imodel=prev_i, kernel=KERNEL_GRAM, **kw)
+        ci = mat.column_stats()
+        assert si["kernel"] == KERNEL_GRAM and (si["gram_build_ms"] > 0) == (step == 0)
+        assert np.array_equal(ci.nacols[tile], so["nacols"][tile])
+        assert (ci.sweeps[tile] == so["sweeps"][tile]).mean() >= 0.98
+        assert maxdiff(Wi[:, tile], Wo[:, tile]) <= 2e-5
+        assert abs(si["objval"] - st["objval"]) <= 1e-4 * st["objval"]
+        prev_i = Wi
         if step == 1:
             assert sweeps_g.max() <= 2          # an l2 step of 0.4 moves nothing: one sweep
+            assert ci.sweeps[tile].max() <= 2
             os.environ["SLIM_GPU_FOLD"] = "col"  # the other fold: the same step again
             try:
-                Wc, _ = mat.learn(columns=tile, niters=10000, seed=1, imodel=prev_g, **kw)
+                Wc, _ = mat.learn(columns=tile, niters=10000, seed=1, imodel=prev_g, kernel=KERNEL_TILE, **kw)
             finally:
                 del os.environ["SLIM_GPU_FOLD"]
             assert np.array_equal(mat.column_stats().sweeps[tile], sweeps_g)

@@ -18,8 +18,8 @@ import scipy.sparse as sp
 import slim_oracle as O
 from slim_amd import SLIM, SLIMatrix, _lib
 from slim_amd.constants import SLIM_NOPTIONS, SLIM_OK, Opt
-from slim_amd.engine import (KERNEL_TILE, KERNEL_TILE16, KERNEL_WAVE_HBM, KERNEL_WAVE_LDS,
-                             DeviceMatrix,
+from slim_amd.engine import (KERNEL_GRAM, KERNEL_TILE, KERNEL_TILE16, KERNEL_WAVE_HBM,
+                             KERNEL_WAVE_LDS, DeviceMatrix,
                              model_to_scipy)
 
 pytestmark = pytest.mark.gpu
@@ -463,6 +463,155 @@ def test_screen_sum_cache_changes_nothing(monkeypatch):
         assert warm.nnz == ref_warm.nnz and maxdiff(warm, ref_warm) == 0.0
         assert fs.nnz == ref_fs.nnz and maxdiff(fs, ref_fs) == 0.0
         assert st2["sweeps"] == st_ref["sweeps"]
+
+
+# ---- item-space CD on G = R^T R (cd_gram.hpp) --------------------------------------------------
+# Same update rule, stop rule, cap and visiting order as the tile kernel (the tile's union order),
+# carried over the items instead of the users: checked visit for visit against the oracle's tile
+# walk (reference arithmetic in user space) and against the tile kernel.
+def test_gram_kernel_ml100k_matches_oracle_tile_walk(ml100k, ml_dev, ml_gpu):
+    R, T = ml100k
+    W, st = ml_dev.learn(seed=1, kernel=KERNEL_GRAM)
+    cs = ml_dev.column_stats()
+    assert st["kernel"] == KERNEL_GRAM
+    Wo, so, err_o, obj_o = O.learn_cd_tile(R, tileP=32, seed=1, nthreads=8, return_stats=True)
+    assert maxdiff(W, Wo) <= 2e-5 and pattern_diff(W, Wo) <= 8
+    assert (cs.sweeps == so["sweeps"]).mean() >= 0.99
+    assert abs(cs.D.sum() - so["D"].sum()) <= 0.01 * so["D"].sum()
+    assert abs(cs.U.sum() - so["U"].sum()) <= 0.01 * so["U"].sum()
+    assert abs(st["objval"] - obj_o) <= 1e-4 * obj_o and abs(st["error"] - err_o) <= 1e-4 * err_o
+    assert np.array_equal(cs.nacols, ml_gpu[2].nacols) and np.array_equal(cs.G, ml_gpu[2].G)
+    assert "%.5e" % st["objval"] == "2.29460e+04" and "%.5e" % st["error"] == "2.06490e+04"
+    ev = O.evaluate(W, R, T)
+    assert "%.4f" % ev["hr"] == "0.3191" and "%.4f" % ev["arhr"] == "0.1504"
+    Wt, _ = ml_dev.learn(seed=1, kernel=KERNEL_GRAM, optTol=1e-12, niters=100000)
+    Wr = O.learn_cd(R, order=O.ORDER_PERM, seed=7, aty=O.ATY_GRAM, optTol=1e-12,
+                    maxniters=100000, nthreads=8)
+    assert maxdiff(Wt, Wr) <= 2e-5
+    ids_t, sc_t = O.predict(Wt, R, 10)
+    ids_r, sc_r = O.predict(Wr, R, 10)
+    assert np.abs(sc_t - sc_r).max() <= 1e-4 and (ids_t == ids_r).all(axis=1).mean() >= 0.99
+    # column ranges that are not multiples of 32, a single column, an explicit set, shards
+    parts = [ml_dev.learn(seed=1, kernel=KERNEL_GRAM, optTol=1e-12, niters=100000,
+                          col_begin=b, col_end=e)[0] for b, e in ((0, 37), (37, 38), (38, 200))]
+    got = parts[0] + parts[1] + parts[2]
+    assert maxdiff(got[:, :200], Wt[:, :200]) <= 2e-5 and got[:, 200:].nnz == 0
+    halves = [ml_dev.learn(seed=1, kernel=KERNEL_GRAM, shard=(k, 2))[0] for k in (0, 1)]
+    assert maxdiff(halves[0] + halves[1], W) == 0.0   # a column's walk does not depend on the shards
+
+
+@pytest.mark.parametrize("shape,binary", [((40000, 3000, 0.004), False), ((40000, 6000, 0.003), True),
+                                          ((30000, 15000, 0.002), False), ((20000, 30000, 0.002), True),
+                                          ((20000, 45000, 0.002), True)])
+def test_gram_kernel_geometries_match_tile_kernel(shape, binary):
+    """Every workgroup geometry of the item-space kernel (8 / 16 wavefronts, 2 / 5 / 10 float4 of a
+    row of G per thread; 45 000 items: g no longer fits the LDS and lives in HBM), cold and
+    warm-started, valued and binary, against the tile kernel
+    walking the same tiles: same active sets, same sweep counts, <= 5e-5."""
+    R = _random_ratings(shape[0], shape[1], shape[2], 5)
+    if binary:
+        R.data[:] = 1.0
+    m = DeviceMatrix.from_scipy(R, binary=binary)
+    Wg, sg = m.learn(seed=2, kernel=KERNEL_GRAM)
+    cg = m.column_stats()
+    assert sg["kernel"] == KERNEL_GRAM and sg["gram_build_ms"] > 0
+    Wt, st = m.learn(seed=2, kernel=KERNEL_TILE, cluster=1)
+    ct = m.column_stats()
+    assert Wg.nnz > 10000 and maxdiff(Wg, Wt) <= 5e-5
+    assert np.array_equal(cg.nacols, ct.nacols)
+    assert (cg.sweeps == ct.sweeps).mean() >= 0.98 and cg.D.sum() == pytest.approx(ct.D.sum(), rel=1e-2)
+    assert abs(sg["objval"] - st["objval"]) <= 1e-4 * st["objval"]
+    first, _ = m.learn(seed=2, kernel=KERNEL_TILE, cluster=1, l1r=3.0, l2r=1.0)
+    Wg2, sg2 = m.learn(seed=2, kernel=KERNEL_GRAM, l1r=1.0, l2r=0.5, imodel=first)
+    cg2 = m.column_stats()
+    assert sg2["gram_build_ms"] == 0                      # G stays with the handle
+    Wt2, st2 = m.learn(seed=2, kernel=KERNEL_TILE, cluster=1, l1r=1.0, l2r=0.5, imodel=first)
+    ct2 = m.column_stats()
+    assert maxdiff(Wg2, Wt2) <= 5e-5 and (cg2.sweeps == ct2.sweeps).mean() >= 0.98
+    assert abs(sg2["objval"] - st2["objval"]) <= 1e-4 * st2["objval"]
+    m.close()
+
+
+def test_gram_kernel_warm_start_matches_oracle_tile_walk():
+    """Warm start in item space (g -= x_j G[j, :] for the previous coefficients of the coordinates
+    active now) against oracle_learn_cd_tile(..., imodel) (estimate.c:453-464, cd.c:108-110)."""
+    for binary in (False, True):
+        R = _random_ratings(60000, 96, 0.08, 11)
+        if binary:
+            R.data[:] = 1.0
+        m = DeviceMatrix.from_scipy(R, binary=binary)
+        first_o = O.learn_cd_tile(R, tileP=32, seed=3, nthreads=8, l1r=3.0, l2r=1.0, binary=binary)
+        Wo, so, _, obj_o = O.learn_cd_tile(R, tileP=32, seed=3, nthreads=8, l1r=1.0, l2r=0.5,
+                                           imodel=first_o, return_stats=True, binary=binary)
+        first, _ = m.learn(seed=3, kernel=KERNEL_GRAM, l1r=3.0, l2r=1.0)
+        assert maxdiff(first, first_o) <= 5e-5
+        W, st = m.learn(seed=3, kernel=KERNEL_GRAM, l1r=1.0, l2r=0.5, imodel=first)
+        cs = m.column_stats()
+        assert maxdiff(W, Wo) <= 5e-5 and np.array_equal(cs.nacols, so["nacols"])
+        assert (cs.sweeps == so["sweeps"]).mean() >= 0.98
+        assert abs(st["objval"] - obj_o) <= 1e-4 * obj_o
+        m.close()
+
+
+def test_gram_kernel_is_chosen_for_repeated_solves_only(monkeypatch):
+    """KERNEL_AUTO: the tile kernel for a first solve; item-space CD once the same columns come
+    again, or at once when the caller announced a grid (SLIMGPU_MatrixExpectSolves, what
+    Py_SLIM_Mselect / slim_mselect do); never for FSLIM; SLIM_GPU_NO_GRAMCD=1 turns it off."""
+    R = _random_ratings(40000, 3000, 0.004, 5)      # 4 * (40000 + 2 * 3008) > 64 KiB: no LDS kernel
+    m = DeviceMatrix.from_scipy(R)
+    W1, s1 = m.learn(seed=2)
+    assert s1["kernel"] == KERNEL_TILE
+    W2, s2 = m.learn(seed=2, l2r=0.5)               # the same work list again: a grid is under way
+    assert s2["kernel"] == KERNEL_GRAM and s2["gram_build_ms"] > 0
+    W3, s3 = m.learn(seed=2, l2r=0.5, nnbrs=20)     # FSLIM stays on the tile kernel
+    assert s3["kernel"] == KERNEL_TILE
+    with pytest.raises(RuntimeError):
+        m.learn(seed=2, kernel=KERNEL_GRAM, nnbrs=20)
+    m.close()
+    m = DeviceMatrix.from_scipy(R)
+    m.expect_solves(45)
+    W4, s4 = m.learn(seed=2)
+    assert s4["kernel"] == KERNEL_GRAM and maxdiff(W4, W1) <= 5e-5
+    m.close()
+    monkeypatch.setenv("SLIM_GPU_NO_GRAMCD", "1")
+    m = DeviceMatrix.from_scipy(R)
+    m.expect_solves(45)
+    assert m.learn(seed=2)[1]["kernel"] == KERNEL_TILE
+    m.close()
+
+
+@pytest.mark.parametrize("kernel", [KERNEL_WAVE_LDS, KERNEL_WAVE_HBM, KERNEL_TILE, KERNEL_GRAM])
+def test_negative_previous_coefficients_start_at_zero(kernel):
+    """estimate.c:456-464: a negative entry of the previous model is copied into x and then reset
+    to 0 by the flag-clearing loop -- a warm start from a model with negative entries is a warm
+    start from the same model with those entries removed.  (The engine's own models hold none;
+    a caller's may.)"""
+    R = _random_ratings(3000, 400, 0.03, 11)
+    m = DeviceMatrix.from_scipy(R)
+    first, _ = m.learn(l1r=3.0, l2r=1.0, seed=9, kernel=kernel)
+    bad = first.copy().tolil()
+    cols = first.tocoo()
+    for k in range(0, cols.nnz, 7):                 # every 7th coefficient becomes negative
+        bad[cols.row[k], cols.col[k]] = -0.25
+    bad = sp.csc_matrix(bad)
+    dropped = bad.copy()
+    dropped.data[dropped.data < 0] = 0.0
+    dropped.eliminate_zeros()
+    Wb, _ = m.learn(l1r=1.0, l2r=0.5, seed=9, kernel=kernel, imodel=bad)
+    Wd, _ = m.learn(l1r=1.0, l2r=0.5, seed=9, kernel=kernel, imodel=dropped)
+    assert maxdiff(Wb, Wd) == 0.0
+    # the oracle in the reference's own form (per item, estimate.c:453-464 as written) and its
+    # tile walk treat the negative entries the same way
+    Wo = O.learn_cd(R, l1r=1.0, l2r=0.5, order=O.ORDER_PERM, seed=9, aty=O.ATY_GRAM, nthreads=8,
+                    imodel=bad)
+    Wo_d = O.learn_cd(R, l1r=1.0, l2r=0.5, order=O.ORDER_PERM, seed=9, aty=O.ATY_GRAM, nthreads=8,
+                      imodel=dropped)
+    assert maxdiff(Wo, Wo_d) == 0.0
+    assert maxdiff(O.learn_cd_tile(R, tileP=32, seed=9, nthreads=8, l1r=1.0, l2r=0.5, imodel=bad),
+                   O.learn_cd_tile(R, tileP=32, seed=9, nthreads=8, l1r=1.0, l2r=0.5, imodel=dropped)) == 0.0
+    if kernel in (KERNEL_WAVE_LDS, KERNEL_WAVE_HBM):
+        assert maxdiff(Wb, Wo) <= 5e-5
+    m.close()
 
 
 def test_tile_kernel_ratings_and_warm_start():
