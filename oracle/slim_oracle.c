@@ -227,6 +227,13 @@ typedef struct {
  * oracle_learn_cd / oracle_learn_cd_tile call, without the setup (transpose, norms) */
 static double g_learn_seconds = 0.0;
 double oracle_learn_seconds(void) { return g_learn_seconds; }
+/* Timing aid (bench.py's bounded CPU sample): a wall-clock budget for the estimate phase of the
+ * NEXT oracle_learn_cd call.  Past it no new sweep starts: a column that was cut off reports
+ * conv = -1 and the D it had reached, a column that never started conv = -2 -- the caller turns
+ * partial columns into fractions of a column.  0 (the default) = no budget; results of a
+ * budgeted call are not models and are never compared with anything. */
+static double g_time_budget = 0.0, g_deadline = 0.0;
+void oracle_set_time_budget(double seconds) { g_time_budget = seconds > 0.0 ? seconds : 0.0; }
 static double now_seconds(void) {
 #ifdef _OPENMP
   return omp_get_wtime();
@@ -371,6 +378,10 @@ static int32_t cd_reference(const cview_t *A, const oracle_cfg_t *cfg,
   for (t = 0; t < maxniters; t++) {
     double dltx = 0.0;
     const fkv_t *visit = act;
+    if (g_deadline > 0.0 && now_seconds() > g_deadline) { /* oracle_set_time_budget */
+      rstatus = -1;
+      break;
+    }
     if (cfg->order == ORDER_GLIBC)
       shuffle_glibc(act, na); /* cd.c:115 */
     else if (cfg->order == ORDER_LOCAL)
@@ -512,6 +523,8 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
 
   const int chunk = cfg->chunk > 0 ? cfg->chunk : 32;
   const double t_learn0 = now_seconds();
+  g_deadline = g_time_budget > 0.0 ? t_learn0 + g_time_budget : 0.0;
+  g_time_budget = 0.0; /* one call only */
 #pragma omp parallel num_threads(nthreads) reduction(+ : error, objval)
   {
     /* per-thread dense work vectors, estimate.c:382-385 */
@@ -539,6 +552,10 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
       const int32_t iC = colsel ? colsel[w] : w;
       const int64_t cs = colptr[iC], ce = colptr[iC + 1];
       int64_t G = 0, D = 0, U = 0;
+      if (g_deadline > 0.0 && now_seconds() > g_deadline) { /* budget spent: not started */
+        if (stats) stats[iC].conv = -2;
+        continue;
+      }
 
       /* estimate.c:406-408 target vector */
       for (int64_t j = cs; j < ce; j++)
@@ -710,6 +727,7 @@ int32_t oracle_learn_cd(int32_t nrows, const int64_t *rowptr,
     free(ncand);
   }
   g_learn_seconds = now_seconds() - t_learn0;
+  g_deadline = 0.0;
 
   /* estimate.c:570-589 SaveModel, column view */
   int64_t tnnz = 0;
@@ -937,6 +955,7 @@ int32_t oracle_learn_cd_tile_warm(int32_t nrows, const int64_t *rowptr,
     free(x); free(y); free(yhat); free(ATy); free(nmark); free(ncand);
   }
   g_learn_seconds = now_seconds() - t_learn0;
+  g_deadline = 0.0;
   free(key); free(act); free(uni); free(Gm);
 
   int64_t tnnz = 0;

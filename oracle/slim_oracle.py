@@ -62,6 +62,8 @@ def lib():
         _lib.oracle_perm_index.argtypes = [C.c_uint32] * 3
         _lib.oracle_max_threads.restype = C.c_int32
         _lib.oracle_free.argtypes = [C.c_void_p]
+        _lib.oracle_set_time_budget.argtypes = [C.c_double]
+        _lib.oracle_set_time_budget.restype = None
     return _lib
 
 
@@ -280,6 +282,13 @@ def cache_setup(on):
     """Keep the column view (transpose + norms) of the last matrix across calls while the SAME
     index array is passed (bench.py's CPU leg on a 1e9-nnz matrix); cache_setup(False) frees it."""
     lib().oracle_cache_setup(C.c_int32(1 if on else 0))
+
+
+def set_time_budget(seconds):
+    """Wall-clock budget of the estimate phase of the NEXT learn_cd call (bench.py's bounded CPU
+    sample): past it no new sweep starts; cut-off columns report conv = -1 (and the D they
+    reached), columns never started conv = -2.  Not for anything that is compared."""
+    lib().oracle_set_time_budget(float(seconds))
 
 
 def learn_seconds():

@@ -275,6 +275,122 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
       }
       float dlt = 0.0f;
       const PermCtx pc = perm_make((uint32_t)nunion, perm_key(S.seed, gkey, (uint32_t)t));
+      if (!LDSG) {
+        // g in HBM: a pass over g per update would move 8 ncols bytes on top of the row's 4.
+        // Batches of 64 MS visits (MS per lane); the updates of a batch are only NOTED (which
+        // lane of which slot, by how much) while every lane keeps the g of its own visits current
+        // from single elements of the rows (below); when the batch is decided, every thread
+        // applies all of its rows to its slices of g in ONE pass -- g is read and written once per
+        // batch, the rows once each, their loads independent of one another.
+        constexpr int MS = 8;
+        for (int p0 = 0; p0 < nunion; p0 += 64 * MS) {
+          __syncthreads();  // the previous batch's pass over g is complete
+          int i[MS], len[MS];
+          float xi[MS], sq[MS], cn[MS], gi[MS], dsv[MS];
+          bool part[MS];
+          uint64_t umask[MS];
+#pragma unroll
+          for (int sl = 0; sl < MS; ++sl) {
+            const int pos = p0 + sl * 64 + lane;
+            const bool valid = pos < nunion;
+            i[sl] = 0;
+            xi[sl] = kInactive;
+            if (valid) {
+              i[sl] = ul[perm_index(pc, (uint32_t)pos)];
+              xi[sl] = x[i[sl]];
+            }
+            part[sl] = valid && tile_active(xi[sl]);
+            sq[sl] = 0.0f;
+            cn[sl] = 0.0f;
+            len[sl] = 0;
+            if (part[sl]) {
+              sq[sl] = A.csq[i[sl]];
+              cn[sl] = A.cnorm[i[sl]];
+              len[sl] = (int)(colptr[i[sl] + 1] - colptr[i[sl]]);
+            }
+            gi[sl] = g[i[sl]];
+            dsv[sl] = 0.0f;
+            umask[sl] = 0ull;
+            Dq += (unsigned long long)len[sl];
+          }
+          __syncthreads();  // every wavefront holds its batch: g may change now
+          bool any_upd = false;
+#pragma unroll
+          for (int sl = 0; sl < MS; ++sl) {
+            uint64_t pend = __ballot(part[sl]);
+            while (pend) {
+              const float xeff = (xi[sl] > kEps || xi[sl] < -kEps) ? xi[sl] : 0.0f;
+              const float num = gi[sl] + xeff * sq[sl];
+              const float nx = num > l1 ? (num - l1) / (cn[sl] * cn[sl] + l2) : 0.0f;
+              const float neff = (nx > kEps || nx < -kEps) ? nx : 0.0f;
+              const float d = neff - xeff;
+              const uint64_t m = __ballot(part[sl] && nx != xi[sl]) & pend;
+              if (m == 0) break;
+              const int f = __builtin_ctzll(m);
+              const int i_f = lane_bcast(i[sl], f);
+              const float d_f = lane_bcast(d, f);
+              const float nx_f = lane_bcast(nx, f), xi_f = lane_bcast(xi[sl], f);
+              dlt += (nx_f - xi_f) * (nx_f - xi_f);
+              if (wave == 0 && lane == f) x[i[sl]] = nx;
+              pend = f == 63 ? 0ull : (pend & ~((2ull << f) - 1ull));
+              if (d_f != 0.0f) {
+                if (lane == f) {
+                  Uq += (unsigned long long)len[sl];
+                  dsv[sl] = d_f;
+                }
+                umask[sl] |= 1ull << f;
+                any_upd = true;
+                // the visits still ahead (the rest of this slot, every later slot) see the update
+                // through one element of the row each
+                const float* __restrict__ row = Gm + (int64_t)i_f * ld;
+#pragma unroll
+                for (int s2 = 0; s2 < MS; ++s2)
+                  if (s2 >= sl) gi[s2] = fmaf(-d_f, row[i[s2]], gi[s2]);
+              }
+            }
+          }
+          if (any_upd) {  // one pass over g for all the rows of the batch, in visiting order
+            constexpr int CS = 4;
+            for (int c0 = tid; c0 < n4; c0 += CS * NT) {
+              float4 gv[CS];
+#pragma unroll
+              for (int j = 0; j < CS; ++j) {
+                const int c = c0 + j * NT;
+                gv[j] = g4[c < n4 ? c : c0];
+              }
+#pragma unroll
+              for (int sl = 0; sl < MS; ++sl) {
+                uint64_t mm = umask[sl];
+                while (mm) {
+                  const int f = __builtin_ctzll(mm);
+                  mm &= mm - 1ull;
+                  const int i_f = lane_bcast(i[sl], f);
+                  const float d_f = lane_bcast(dsv[sl], f);
+                  const float4* __restrict__ r4 = reinterpret_cast<const float4*>(Gm + (int64_t)i_f * ld);
+                  float4 rv[CS];
+#pragma unroll
+                  for (int j = 0; j < CS; ++j) {
+                    const int c = c0 + j * NT;
+                    rv[j] = r4[c < n4 ? c : c0];
+                  }
+#pragma unroll
+                  for (int j = 0; j < CS; ++j) {
+                    gv[j].x = fmaf(-d_f, rv[j].x, gv[j].x);
+                    gv[j].y = fmaf(-d_f, rv[j].y, gv[j].y);
+                    gv[j].z = fmaf(-d_f, rv[j].z, gv[j].z);
+                    gv[j].w = fmaf(-d_f, rv[j].w, gv[j].w);
+                  }
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < CS; ++j) {
+                const int c = c0 + j * NT;
+                if (c < n4) g4[c] = gv[j];
+              }
+            }
+          }
+        }
+      } else
       for (int p0 = 0; p0 < nunion; p0 += 64) {
         __syncthreads();  // every thread's row updates of the previous batch are in LDS
         const int pos = p0 + lane;

@@ -351,6 +351,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         const int64_t cs = uni(csplit[(int64_t)i * (K + 1) + mk]);
         const int64_t ce = uni(csplit[(int64_t)i * (K + 1) + mk + 1]);
         float acc = 0.0f;
+        bool co = false;  // FSLIM: a user of the problem's item rated column i (neighbors.c:46-60)
         // ids / values of the next block are requested before the current one is consumed
         int u_n = 0;
         float v_n = 0.0f;
@@ -395,11 +396,19 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
               const int src = t0 + g * SL + slot;
               const float w = HAS_VAL ? __shfl(cw, src & 63) : 1.0f;
               acc += w * rr[g];
+              if (FSLIM && HAS_VAL) co = co || rr[g] != 0.0f;
             }
           }
         }
         if (SL == 4) acc += __shfl_xor(acc, 16);
         acc += __shfl_xor(acc, 32);
+        if (FSLIM && HAS_VAL) {
+          // ratings that cancel: a co-rated column whose sum is 0 stays a candidate -- the sign
+          // bit of the zero carries it through the partial buffer
+          if (SL == 4) co = co || (__shfl_xor((int)co, 16) != 0);
+          co = co || (__shfl_xor((int)co, 32) != 0);
+          if (acc == 0.0f && co) acc = -0.0f;
+        }
         if (slot == 0) part[(int64_t)i * P + q] = acc;  // one 128-byte line per column
       }
     }
@@ -428,14 +437,22 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         const int i = (int)(idx >> LOGP), qq = (int)(idx & (P - 1));
         const int it = s_item[qq];
         float a = 0.0f;
+        bool co = false;
         if (cached) {
           a = gram_t[idx];
+          co = a != 0.0f || __builtin_signbit(a);
         } else {
-          for (int k = 0; k < K; ++k) a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
+          for (int k = 0; k < K; ++k) {
+            const float pk = S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
+            a += pk;
+            co = co || pk != 0.0f || __builtin_signbit(pk);
+          }
+          if (a == 0.0f) a = co ? -0.0f : 0.0f;  // (-0 + 0 = +0: restore the mark)
           if (gram_t != nullptr && mk == 0) gram_t[idx] = a;
         }
         float sim = kInactive;
-        if (it >= 0 && i != it && a != 0.0f) {
+        // candidates: the co-rated columns (neighbors.c:46-60), also when the sum cancelled
+        if (it >= 0 && i != it && co) {
           const float cn_i = A.cnorm[i];
           sim = S.simtype == 0 ? a / cn_i : (S.simtype == 1 ? a / ((cn_i + s_cn[qq]) - a) : a);
         }

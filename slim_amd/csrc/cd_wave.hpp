@@ -247,8 +247,15 @@ __global__ __launch_bounds__(64) void cd_wave_kernel(const DevMatrix A, const So
         float acc = 0.0f;
         if (i < ncols) {
           const int64_t s = A.colptr[i], e = A.colptr[i + 1];
-          for (int64_t k = s; k < e; ++k) acc += (HAS_VAL ? A.colval[k] : 1.0f) * r[A.colind[k]];
-          aty[i] = acc;
+          bool co = false;  // a user of iC rated i too (their products may still cancel)
+          for (int64_t k = s; k < e; ++k) {
+            const float yv = r[A.colind[k]];
+            acc += (HAS_VAL ? A.colval[k] : 1.0f) * yv;
+            co = co || yv != 0.0f;
+          }
+          // FSLIM's candidates are the CO-RATED items, whatever their sum (neighbors.c:46-60):
+          // a sum that cancelled to 0 is kept apart from "no common user" by its sign bit
+          aty[i] = (acc == 0.0f && co) ? -0.0f : acc;
         }
       }
     } else {
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(64) void cd_wave_kernel(const DevMatrix A, const So
       for (int i = lane; i < ncols; i += 64) {
         const float a = aty[i];
         float sim = ninf;
-        if (a != 0.0f && i != iC) {
+        if ((a != 0.0f || __builtin_signbit(a)) && i != iC) {
           const float cn_i = A.cnorm[i];
           sim = S.simtype == 0 ? a / cn_i : (S.simtype == 1 ? a / ((cn_i + cn_c) - a) : a);
         }

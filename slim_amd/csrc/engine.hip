@@ -38,6 +38,7 @@ struct slimgpu_matrix {
   bool binary = false;
   bool owns_csr = false;
   bool exact_gram = false;  // ratings are not small integers: aTy sums formed in a fixed order
+  bool nonpositive = false;  // some rating is <= 0: a co-rating sum can cancel to exactly 0
   // CSR
   int64_t* d_rowptr = nullptr;
   int32_t* d_rowind = nullptr;
@@ -241,6 +242,9 @@ __global__ void k_col_scalars(int32_t ncols, const int64_t* __restrict__ colptr,
       // float sums of products of small integers are exact in any order; anything else
       // (fractional ratings, huge values) must not be accumulated with float atomics
       if (v != rintf(v) || fabsf(v) > 2048.0f) atomicOr(inexact, 1);
+      // (bit 1: a rating <= 0 -- co-rating sums can then cancel to 0, which matters to FSLIM's
+      // candidate rule, neighbors.c:46-60)
+      if (!(v > 0.0f)) atomicOr(inexact, 2);
       const int32_t u = colind[k];
       g += rowptr[u + 1] - rowptr[u];
     }
@@ -382,7 +386,8 @@ void build_column_view(slimgpu_matrix* m) {
       // the reference walks duplicates as separate entries (norm from v1^2 + v2^2, dots from
       // v1 + v2): not a well-defined problem, and two lanes updating one residual race here
       (void)hipFree(d_cost);
-      throw InputError{"duplicate (user, item) entries in the rating matrix"};
+      throw InputError{"duplicate (user, item) entries in the rating matrix (SLIM_GPU_DUPLICATES=sum "
+                       "merges them while a host matrix is staged)"};
     }
   } else {
     HIP_TRY(hipMemsetAsync(m->d_colptr, 0, sizeof(int64_t) * ((size_t)m->ncols + 1), st));
@@ -401,7 +406,8 @@ void build_column_view(slimgpu_matrix* m) {
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipFree(d_cost));
   HIP_TRY(hipFree(d_inexact));
-  m->exact_gram = h_inexact != 0;
+  m->exact_gram = (h_inexact & 1) != 0;
+  m->nonpositive = (h_inexact & 2) != 0;
 }
 
 // user ranges of equal nnz + per-column slice boundaries for clusters of size K = 1 << lg
@@ -515,6 +521,53 @@ slimgpu_matrix_t* matrix_from_host(int32_t nrows, const ssize_t* rowptr, const i
   }
   auto* m = new slimgpu_matrix();
   const double t0 = now_ms();
+  // Repeated (user, item) pairs.  The reference copies them verbatim (setup.c:119-126) and then
+  // treats them inconsistently -- the LAST value of a pair is the target y[u] (estimate.c:406-408),
+  // dot products take both entries, the norm is v1^2 + v2^2 -- and two lanes updating one
+  // residual would race here, so the engine rejects them (default) or, with
+  // SLIM_GPU_DUPLICATES=sum, merges them before staging: the values of a pair are added
+  // (an implicit-feedback matrix, rowval == NULL, keeps one entry and stays binary).
+  std::vector<int64_t> mptr;
+  std::vector<int32_t> mind;
+  std::vector<float> mval;
+  if (const char* e = std::getenv("SLIM_GPU_DUPLICATES"); e && std::strcmp(e, "sum") == 0 && nrows > 0) {
+    bool any = false;
+    std::vector<std::pair<int32_t, float>> row;
+    mptr.assign((size_t)nrows + 1, 0);
+    mind.reserve((size_t)rowptr[nrows]);
+    if (rowval) mval.reserve((size_t)rowptr[nrows]);
+    for (int32_t u = 0; u < nrows; ++u) {
+      const int64_t s0 = rowptr[u], e0 = rowptr[u + 1];
+      row.clear();
+      for (int64_t k = s0; k < e0; ++k) row.emplace_back(rowind[k], rowval ? rowval[k] : 1.0f);
+      bool sorted = true;
+      for (size_t k = 1; k < row.size(); ++k) sorted = sorted && row[k - 1].first < row[k].first;
+      if (!sorted) {  // (strictly ascending rows hold no repeated pair and are copied as they are)
+        std::stable_sort(row.begin(), row.end(),
+                         [](const auto& a, const auto& b) { return a.first < b.first; });
+        size_t w = 0;
+        for (size_t k = 0; k < row.size(); ++k) {
+          if (w > 0 && row[w - 1].first == row[k].first) {
+            if (rowval) row[w - 1].second += row[k].second;
+            any = true;
+          } else {
+            row[w++] = row[k];
+          }
+        }
+        row.resize(w);
+      }
+      for (const auto& pr : row) {
+        mind.push_back(pr.first);
+        if (rowval) mval.push_back(pr.second);
+      }
+      mptr[(size_t)u + 1] = (int64_t)mind.size();
+    }
+    if (any) {  // stage the merged copy (rows now ascending by item id)
+      rowptr = reinterpret_cast<const ssize_t*>(mptr.data());
+      rowind = mind.data();
+      if (rowval) rowval = mval.data();
+    }
+  }
   try {
     pick_device(m, opt);
     m->nrows = nrows;
@@ -634,6 +687,7 @@ slimgpu_matrix_t* matrix_clone_to_device(const slimgpu_matrix_t* src, int32_t de
     m->nnz = src->nnz;
     m->binary = src->binary;
     m->exact_gram = src->exact_gram;
+    m->nonpositive = src->nonpositive;
     m->owns_csr = true;
     m->h_cost = src->h_cost;
     const size_t nz = (size_t)std::max<int64_t>(m->nnz, 1);
@@ -645,9 +699,37 @@ slimgpu_matrix_t* matrix_clone_to_device(const slimgpu_matrix_t* src, int32_t de
     m->d_colval = m->binary ? nullptr : dev_alloc<float>(nz);
     m->d_cnorm = dev_alloc<float>((size_t)m->ncols);
     m->d_csq = dev_alloc<float>((size_t)m->ncols);
+    // device to device over xGMI when the two devices can reach each other (asked, not
+    // assumed: a partitioned node or an IOMMU setting can say no), else through a pinned host
+    // buffer, 256 MB at a time -- slower, never wrong.  SLIM_GPU_PEER=0 forces the host route.
+    int can_peer = m->device == src->device ? 1 : 0;
+    if (!can_peer) {
+      if (hipDeviceCanAccessPeer(&can_peer, m->device, src->device) != hipSuccess) can_peer = 0;
+      (void)hipGetLastError();
+    }
+    if (const char* e = std::getenv("SLIM_GPU_PEER")) can_peer = can_peer && std::atoi(e) != 0;
+    void* bounce = nullptr;
+    const size_t bounce_bytes = size_t(256) << 20;
+    struct BounceFree {
+      void** p;
+      ~BounceFree() {
+        if (*p) (void)hipHostFree(*p);
+      }
+    } bounce_guard{&bounce};
     auto peer = [&](void* dst, const void* from, size_t bytes) {
       if (bytes == 0 || !dst || !from) return;
-      HIP_TRY(hipMemcpyPeerAsync(dst, m->device, from, src->device, bytes, m->stream));
+      if (can_peer) {
+        HIP_TRY(hipMemcpyPeerAsync(dst, m->device, from, src->device, bytes, m->stream));
+        return;
+      }
+      if (!bounce) HIP_TRY(hipHostMalloc(&bounce, bounce_bytes, hipHostMallocDefault));
+      for (size_t off = 0; off < bytes; off += bounce_bytes) {
+        const size_t n = std::min(bounce_bytes, bytes - off);
+        HIP_TRY(hipSetDevice(src->device));
+        HIP_TRY(hipMemcpy(bounce, static_cast<const char*>(from) + off, n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipSetDevice(m->device));
+        HIP_TRY(hipMemcpy(static_cast<char*>(dst) + off, bounce, n, hipMemcpyHostToDevice));
+      }
     };
     peer(m->d_rowptr, src->d_rowptr, sizeof(int64_t) * ((size_t)m->nrows + 1));
     peer(m->d_colptr, src->d_colptr, sizeof(int64_t) * ((size_t)m->ncols + 1));
@@ -1059,8 +1141,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
       const size_t per_cl = ((tile_r + 2 * tile_x) * sizeof(float) + tile_u * sizeof(int32_t)) * clusterK;
+      // (the screen-sum cache is given up when a workspace does not fit: ws_get evicts it)
       const size_t have = free_b + m->ws_slab.bytes + m->ws_xslab.bytes + m->ws_ulist.bytes +
-                          m->ws_part.bytes;
+                          m->ws_part.bytes + m->ws_gram.bytes;
       const size_t budget = have > (size_t(6) << 30) ? have - (size_t(6) << 30) : have / 2;
       if ((size_t)nclusters * per_cl > budget) {
         nclusters = (int)std::max<size_t>(1, budget / per_cl);
@@ -1093,11 +1176,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     size_t mailbox_words = 0;
     auto alloc_tiles = [&]() {
       mailbox_words = (size_t)(std::max(nclusters, 1) + nclusters_hi) * mailbox_stride;
-      d_slab = ws_get<float>(m->ws_slab, tile_r * (size_t)nwaves);
-      d_xslab = ws_get<float>(m->ws_xslab, tile_x * (size_t)nwaves);
-      d_ulist = ws_get<int32_t>(m->ws_ulist, tile_u * (size_t)nwaves);
-      d_mailbox = ws_get<unsigned long long>(m->ws_mailbox, mailbox_words);
-      d_part = ws_get<float>(m->ws_part, tile_x * (size_t)nwaves);
+      d_slab = ws_get<float>(m->ws_slab, tile_r * (size_t)nwaves, m);
+      d_xslab = ws_get<float>(m->ws_xslab, tile_x * (size_t)nwaves, m);
+      d_ulist = ws_get<int32_t>(m->ws_ulist, tile_u * (size_t)nwaves, m);
+      d_mailbox = ws_get<unsigned long long>(m->ws_mailbox, mailbox_words, m);
+      d_part = ws_get<float>(m->ws_part, tile_x * (size_t)nwaves, m);
       // LDS user bitmap of the screen pass: one bit per 2^shift users of a member's range,
       // at most kBitmapBytes
       const int64_t range = (int64_t)(tile_r / (size_t)tileP);
@@ -1211,7 +1294,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       } else {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if (need <= (size_t(64) << 30) && need <= (free_b + m->ws_gram.bytes) / 2) {
+        // (a quarter of what is free, 32 GB at most: a second handle or a replica on the same
+        // device must still find room -- and the cache is dropped whenever a workspace needs it)
+        if (need <= (size_t(32) << 30) && need <= (free_b + m->ws_gram.bytes) / 4) {
           m->gram_order.clear();  // (invalid while it is being rewritten)
           d_gram = ws_get<float>(m->ws_gram, need / sizeof(float));
           gram_mode = 1;
@@ -1222,8 +1307,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     bool cluster_fallback = false;
     for (int attempt = 0; attempt < 8 && !pending.empty(); ++attempt) {
       const int32_t npend = (int32_t)pending.size();
-      int32_t* d_ai = ws_get<int32_t>(m->ws_arena_i, (size_t)arena_cap);
-      float* d_av = ws_get<float>(m->ws_arena_v, (size_t)arena_cap);
+      int32_t* d_ai = ws_get<int32_t>(m->ws_arena_i, (size_t)arena_cap, m);
+      float* d_av = ws_get<float>(m->ws_arena_v, (size_t)arena_cap, m);
       HIP_TRY(hipMemcpyAsync(d_order, pending.data(), sizeof(int32_t) * (size_t)npend,
                              hipMemcpyHostToDevice, stream));
       HIP_TRY(hipMemsetAsync(d_misc, 0, sizeof(int32_t) * 16, stream));
@@ -1257,7 +1342,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.ubounds = use_tile ? m->d_ubounds[cluster_lg] : nullptr;
       S.csplit = use_tile ? m->d_csplit[cluster_lg] : nullptr;
       S.mailbox = d_mailbox;
-      S.exact_gram = (m->exact_gram || std::getenv("SLIM_GPU_EXACT_GRAM")) ? 1 : 0;
+      // (FSLIM on ratings that can cancel: the fixed-order pass also counts co-ratings, so that
+      // a candidate whose sum is 0 stays a candidate -- neighbors.c:46-60 marks every co-rated item)
+      S.exact_gram = (m->exact_gram || std::getenv("SLIM_GPU_EXACT_GRAM") ||
+                      (opt.nnbrs > 0 && m->nonpositive)) ? 1 : 0;
       S.atypart = d_part;
       S.bm_shift = bm_shift;
       S.bm_words = bm_words;
@@ -1330,7 +1418,12 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       }
       // members of a cluster on one XCD (one L2): matters for the row-wise fold, whose x lines
       // are shared by the cluster; placement only, never correctness
-      if (use_tile && clusterK > 1 && launch_now % 8 == 0) {
+      // (8 XCDs of 32 CUs on this part; asked of the device as CUs / 32, so that a partition mode
+      // or another part does not get a placement that straddles XCDs: clusters must tile an XCD's
+      // share of the launch)
+      const int nxcd = m->num_cus % 32 == 0 ? m->num_cus / 32 : 1;
+      if (use_tile && clusterK > 1 && nxcd == 8 && launch_now % 8 == 0 &&
+          (launch_now / 8) % clusterK == 0 && (S.nheavy == 0 || (launch_now / 8) % clusterHi == 0)) {
         S.xcd_swizzle = 1;
         if (const char* e = std::getenv("SLIM_GPU_XCD")) S.xcd_swizzle = std::atoi(e) != 0;
       }

@@ -884,6 +884,92 @@ def test_fslim_tile_kernel_matches_oracle(ml100k, ml_dev, automotive, simtype, c
         m.close()
 
 
+@pytest.mark.parametrize("kernel,cluster", [(KERNEL_WAVE_LDS, None), (KERNEL_WAVE_HBM, None),
+                                            (KERNEL_TILE, 1), (KERNEL_TILE, 4)])
+def test_fslim_candidates_are_the_co_rated_items(kernel, cluster):
+    """neighbors.c:46-60 marks every item that shares a user with the target as a candidate,
+    whatever the sum of the products: with ratings of both signs a co-rating sum can cancel to
+    exactly 0 and the item is still a neighbour candidate (similarity 0, ahead of nothing but
+    the items never co-rated).  Ratings in {-2, -1, 1, 2} on a small dense matrix cancel often;
+    more neighbours are asked for than candidates with a non-zero sum exist."""
+    rng = np.random.default_rng(5)
+    R = sp.random(300, 48, density=0.3, format="csr", random_state=rng, dtype=np.float32)
+    R.data = rng.choice(np.array([-2.0, -1.0, 1.0, 2.0], np.float32), R.nnz)
+    R.sort_indices()
+    G = (R.T @ R).toarray()
+    co = ((abs(R).T @ abs(R)).toarray() > 0)
+    np.fill_diagonal(co, False)
+    cancelled = int((co & (G == 0)).sum())
+    assert cancelled >= 20                         # the case is exercised
+    m = DeviceMatrix.from_scipy(R)
+    geom = {} if cluster is None else {"cluster": cluster}
+    for simtype in (0, 2):
+        W, st = m.learn(l1r=0.1, l2r=1.0, seed=4, nnbrs=40, simtype=simtype, kernel=kernel, niters=200, **geom)
+        cs = m.column_stats()
+        if kernel == KERNEL_TILE:
+            Wo, so, _, _ = O.learn_cd_tile(R, tileP=32, l1r=0.1, l2r=1.0, maxniters=200, seed=4, nthreads=4,
+                                           nnbrs=40, simtype=simtype, return_stats=True)
+        else:
+            Wo, so, _, _ = O.learn_cd(R, l1r=0.1, l2r=1.0, maxniters=200, order=O.ORDER_PERM, seed=4,
+                                      aty=O.ATY_GRAM, nthreads=4, nnbrs=40, simtype=simtype,
+                                      return_stats=True)
+        want = np.minimum(co.sum(axis=0), 40)      # every co-rated item is a candidate
+        assert np.array_equal(so["nacols"][:48], want)
+        assert np.array_equal(cs.nacols[:48], so["nacols"][:48])
+        assert maxdiff(W, Wo) <= 5e-5
+    m.close()
+
+
+def test_repeated_pairs_are_rejected_or_summed(monkeypatch):
+    """A CSR with the same (user, item) pair twice: rejected by default (SLIM_ERROR_INPUT); with
+    SLIM_GPU_DUPLICATES=sum the values of a pair are added while the host matrix is staged (an
+    implicit-feedback matrix keeps one entry), i.e. the engine solves the matrix scipy's
+    sum_duplicates() gives -- checked against the oracle on that matrix.  (The reference copies
+    repeated pairs verbatim, setup.c:119-126, and then uses the LAST value as the target, both
+    values in the dot products and v1^2 + v2^2 as the norm: the oracle restates that walk, and
+    its result on the raw matrix is a different model -- shown below.)"""
+    rng = np.random.default_rng(9)
+    base = _random_ratings(3000, 400, 0.03, 11).tocoo()
+    pick = rng.choice(base.nnz, 500, replace=False)
+    rows = np.concatenate([base.row, base.row[pick]])
+    cols = np.concatenate([base.col, base.col[pick]])
+    vals = np.concatenate([base.data, rng.integers(1, 6, pick.size).astype(np.float32)])
+    perm = rng.permutation(rows.size)              # rows unsorted, repeated pairs anywhere in a row
+    o = np.argsort(rows[perm], kind="stable")
+    rows, cols, vals = rows[perm][o], cols[perm][o], vals[perm][o]
+    ptr = np.zeros(3001, np.int64)
+    np.add.at(ptr, rows + 1, 1)
+    raw = sp.csr_matrix((vals, cols.astype(np.int32), np.cumsum(ptr)), shape=(3000, 400))
+    assert raw.nnz == base.nnz + 500 and not raw.has_canonical_format
+    with pytest.raises(RuntimeError, match="duplicate"):
+        DeviceMatrix.from_scipy(raw)
+    merged = raw.copy()
+    merged.sum_duplicates()
+    merged.sort_indices()
+    monkeypatch.setenv("SLIM_GPU_DUPLICATES", "sum")
+    m = DeviceMatrix.from_scipy(raw)
+    assert m.nnz == merged.nnz == base.nnz
+    cp, ci, cv, cn = m.column_view()
+    Mc = merged.tocsc()
+    Mc.sort_indices()
+    assert np.array_equal(ci, Mc.indices) and np.array_equal(cv, Mc.data.astype(np.float32))
+    W, st = m.learn(l1r=2.0, l2r=3.0, seed=9)
+    m.close()
+    ref = DeviceMatrix.from_scipy(merged)
+    Wm, _ = ref.learn(l1r=2.0, l2r=3.0, seed=9)
+    ref.close()
+    assert maxdiff(W, Wm) == 0.0
+    Wo = O.learn_cd(merged, l1r=2.0, l2r=3.0, order=O.ORDER_PERM, seed=9, aty=O.ATY_GRAM, nthreads=8)
+    assert maxdiff(W, Wo) <= 5e-5
+    # implicit feedback: a repeated pair is one entry
+    b = DeviceMatrix.from_scipy(raw, binary=True)
+    assert b.nnz == base.nnz
+    b.close()
+    # the reference's own walk of the raw matrix (oracle, verbatim copy) is another model
+    Wraw = O.learn_cd(raw, l1r=2.0, l2r=3.0, order=O.ORDER_PERM, seed=9, aty=O.ATY_GRAM, nthreads=8)
+    assert maxdiff(Wraw, Wo) > 1e-3
+
+
 def test_output_arena_overflow_is_recovered(ml100k, ml_gpu, monkeypatch):
     """The learned columns land in a device arena sized from nnz(R); if it is too small the
     columns that did not fit are solved again with a larger one.  Force that path."""

@@ -126,6 +126,12 @@ def test_view_staging_path(ml100k, monkeypatch, capfd):
     assert st2 == 1, s2
     assert "staging 'view'" in capfd.readouterr().err
     assert W2.nnz == W1.nnz and maxdiff(W1, W2) == 0.0
+    # devices that cannot reach each other (hipDeviceCanAccessPeer says no; SLIM_GPU_PEER=0 plays
+    # that answer): the finished views travel through a pinned host buffer instead
+    monkeypatch.setenv("SLIM_GPU_PEER", "0")
+    W3, st3, s3 = _slim_learn(R, ngpus=2, L1R=1.0, L2R=1.0)
+    assert st3 == 1, s3
+    assert W3.nnz == W1.nnz and maxdiff(W1, W3) == 0.0
 
 
 def test_explicit_device_wins_over_the_environment(ml100k, monkeypatch):
