@@ -424,6 +424,8 @@ def item_space_grid(args, dev, npairs=3):
                          "G_build_s": round(st["gram_build_ms"] * 1e-3, 2),
                          "kernel": KERNEL_NAMES.get(st["kernel"], st["kernel"]),
                          "sweeps_per_column": round(st["sweeps"] / float(ncols), 2),
+                         "rows_of_G_read": int(st["gram_rows"]),
+                         "row_GBps": round(st["gram_bytes"] / max(st["kernel_ms"], 1e-9) / 1e6, 1),
                          "nnzW": int(st["nnzW"])})
         total = time.perf_counter() - t_all
         mat._lib.SLIM_FreeModel(C.byref(C.c_void_p(prev)))
@@ -436,6 +438,10 @@ def item_space_grid(args, dev, npairs=3):
                 "pairs": recs, "seconds": round(total, 2),
                 "value": npairs * ncols / total, "unit": "item-columns/s",
                 "warm_pair_s": round(sum(warm) / len(warm), 2) if warm else None,
+                "byte_model": "rows_of_G_read x 4 x ncols bytes per solve (one row of G per update and "
+                              "per folded warm-start coefficient; g stays in LDS): row_GBps = that over "
+                              "the kernel time -- above the 8 TB/s of HBM means rows shared by the "
+                              "problems of a tile were served by L2 / Infinity Cache",
                 "note": "round 3, tile kernel (profiles/r03/c5_grid_45pairs.txt): cold pair 157.9 s, "
                         "one-sweep pairs 38-40 s; the whole 45-pair grid: profiles/r04/"}
     finally:

@@ -227,6 +227,10 @@ typedef struct slimgpu_stats_t {
   double error, objval;    /* sum of 1/2||r||^2 and of the objective          */
   double gram_build_ms;    /* SLIMGPU_KERNEL_GRAM: time spent building G = R^T R in
                               this call (0 when it was there already)          */
+  int64_t gram_rows;       /* SLIMGPU_KERNEL_GRAM: rows of G read (one per update and per
+                              folded warm-start coefficient)                   */
+  double gram_bytes;       /* = gram_rows x 4 ncols: that kernel's byte model (it does
+                              not move what SURVEY.md 8(d)'s alg_bytes prices)  */
 } slimgpu_stats_t;
 int32_t SLIMGPU_LastStats(slimgpu_stats_t *out);
 

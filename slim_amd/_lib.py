@@ -27,7 +27,8 @@ class Stats(C.Structure):
                 ("gather_ms", C.c_double), ("total_ms", C.c_double),
                 ("G", C.c_int64), ("D", C.c_int64), ("U", C.c_int64), ("nnzW", C.c_int64),
                 ("sweeps", C.c_int64), ("visits", C.c_int64), ("alg_bytes", C.c_double),
-                ("error", C.c_double), ("objval", C.c_double), ("gram_build_ms", C.c_double)]
+                ("error", C.c_double), ("objval", C.c_double), ("gram_build_ms", C.c_double),
+                ("gram_rows", C.c_int64), ("gram_bytes", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
     //    (a negative value ends up 0 there: the flag-clearing loop resets every x < 0), folded
     //    into g row by row (cd.c:108-110 in item space): g -= x_j G[j, :].  Every thread keeps
     //    its slices of g in registers across the fold; FU rows are in flight together.
+    int64_t nrows_read = 0;  // rows of G read by this problem (fold + updates): the byte model
     if (S.icolptr != nullptr && item < S.incols) {
       const int64_t ws = uni(S.icolptr[item]), we = uni(S.icolptr[item + 1]);
       for (int64_t e = ws + tid; e < we; e += NT) {
@@ -163,6 +164,14 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
         }
       }
       __syncthreads();
+      {
+        int nf = 0;
+        for (int64_t e = ws + lane; e < we; e += 64) {
+          const int k = S.icolind[e];
+          nf += (k < ncols && x[k] > kEps) ? 1 : 0;
+        }
+        nrows_read += (int64_t)(int)wave_sum((float)nf);
+      }
       constexpr int FU = !LDSG ? 4 : (V <= 2 ? 4 : (V <= 5 ? 2 : 1));
       // which row and coefficient entry e folds: entries that fold nothing (past the column,
       // outside the active set, below the epsilon of cd.c:27) read row iC with a zero
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
         // from single elements of the rows (below); when the batch is decided, every thread
         // applies all of its rows to its slices of g in ONE pass -- g is read and written once per
         // batch, the rows once each, their loads independent of one another.
-        constexpr int MS = 8;
+        constexpr int MS = NW == 8 ? 16 : 8;  // (8 wavefronts per workgroup: 256 VGPRs each)
         for (int p0 = 0; p0 < nunion; p0 += 64 * MS) {
           __syncthreads();  // the previous batch's pass over g is complete
           int i[MS], len[MS];
@@ -334,6 +343,7 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
               if (wave == 0 && lane == f) x[i[sl]] = nx;
               pend = f == 63 ? 0ull : (pend & ~((2ull << f) - 1ull));
               if (d_f != 0.0f) {
+                ++nrows_read;
                 if (lane == f) {
                   Uq += (unsigned long long)len[sl];
                   dsv[sl] = d_f;
@@ -428,6 +438,7 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
           if (wave == 0 && lane == f) x[i] = nx;
           pend = f == 63 ? 0ull : (pend & ~((2ull << f) - 1ull));
           if (d_f != 0.0f) {
+            ++nrows_read;
             if (lane == f) Uq += (unsigned long long)len;
             const float* __restrict__ row = Gm + (int64_t)i_f * ld;
             const float4* __restrict__ r4 = reinterpret_cast<const float4*>(row);
@@ -556,6 +567,7 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
         S.st_conv[item] = conv;
         S.st_D[item] = (int64_t)s_D;
         S.st_U[item] = (int64_t)s_U;
+        S.st_G[item] = nrows_read;  // (the engine reports the staging pass's G for the column)
         S.st_err[item] = err;
         S.st_obj[item] = err + (float)reg;
       }

@@ -348,6 +348,10 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     if (!cached) {
       constexpr int GS = 8;  // gather steps in flight per lane (16: no gain, measured)
       for (int i = wave; i < ncols; i += NW) {
+        // building G = R^T R (gram_mode 3): G is symmetric, so a tile only forms the sums of the
+        // columns at or behind its own position in the work list (which then holds every
+        // column); the mirror entries are written below
+        if (S.gram_mode == 3 && uni(S.gram_pos[i]) < base) continue;
         const int64_t cs = uni(csplit[(int64_t)i * (K + 1) + mk]);
         const int64_t ce = uni(csplit[(int64_t)i * (K + 1) + mk + 1]);
         float acc = 0.0f;
@@ -517,11 +521,22 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         float a = 0.0f;  // members in rank order: the same sum on every member
         if (cached) {
           a = gram_t[idx];
+        } else if (S.gram_mode == 3) {
+          // rows item_q of G and, for the columns of later tiles, their mirror entries (the tile
+          // of column i will skip this tile's columns); columns of earlier tiles were skipped
+          const int pi = S.gram_pos[i];
+          if (pi >= base && it >= 0) {
+            for (int k = 0; k < K; ++k)
+              a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
+            if (mk == 0) {
+              S.G[(int64_t)it * S.G_ld + i] = a;
+              if (pi >= base + P) S.G[(int64_t)i * S.G_ld + it] = a;
+            }
+          }
         } else {
           for (int k = 0; k < K; ++k)
             a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
           if (gram_t != nullptr && mk == 0) gram_t[idx] = a;
-          if (S.gram_mode == 3 && mk == 0 && it >= 0) S.G[(int64_t)it * S.G_ld + i] = a;
         }
         const bool act = it >= 0 && i != it && a > l1;
         x[idx] = act ? 0.0f : kInactive;

@@ -924,8 +924,16 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       use_gram = true;
     } else if (kernel == SLIMGPU_KERNEL_AUTO && gram_fits && lds_need > 64 * 1024 &&
                !std::getenv("SLIM_GPU_NO_GRAMCD")) {
-      const bool repeated = m->G_ready || m->expect_solves >= 2 ||
-                            (!m->last_order.empty() && m->last_order == order);
+      bool repeated = m->G_ready || m->expect_solves >= 2 ||
+                      (!m->last_order.empty() && m->last_order == order);
+      // SLIM_GPU_GRAMCD=first: also for a FIRST solve when the byte model says item space wins --
+      // most columns requested (G serves every column; building it costs about one tenth of a
+      // residual sweep) and columns long against the item count (an update moves 4 ncols bytes
+      // there, ~128 nnz(col) bytes for one changed problem of a tile here).  Measured: C5 cold
+      // 158 -> 10 s, C4 whole matrix 579 -> 152 s; C4 at 0.1 % density stays with the tile kernel.
+      if (const char* e = std::getenv("SLIM_GPU_GRAMCD"); e && std::strcmp(e, "first") == 0)
+        repeated = repeated || ((int64_t)nwork * 2 >= ncols &&
+                                (double)m->nnz * 32.0 >= (double)ncols * (double)ncols);
       if (repeated) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -1367,7 +1375,25 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.G = static_cast<float*>(m->ws_G.p);
       S.G_ld = m->G_ld;
       S.tile_nunion = d_nunion;
-      if (opt.build_G) S.gram_mode = 3;
+      S.gram_pos = nullptr;
+      if (opt.build_G) {
+        if (attempt > 0 || cluster_fallback || npend != ncols) {
+          // (the symmetric fill needs every column in ONE launch; a re-plan after a cluster
+          // timeout starts the fill again from the top with the whole list)
+          if (npend != ncols) {
+            set_error("SLIMGPU_Learn: internal: G = R^T R must be built over all columns at once");
+            return fail(SLIM_ERROR);
+          }
+        }
+        std::vector<int32_t> pos((size_t)ncols, 0);
+        for (int32_t t = 0; t < npend; ++t) pos[(size_t)pending[(size_t)t]] = t;
+        int32_t* d_pos = ws_get<int32_t>(m->ws_nunion, (size_t)ncols, m);
+        HIP_TRY(hipMemcpyAsync(d_pos, pos.data(), sizeof(int32_t) * (size_t)ncols,
+                               hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));  // (pos is a local)
+        S.gram_pos = d_pos;
+        S.gram_mode = 3;
+      }
       if (use_gram) {
         S.slab_stride = (int64_t)ncols_pad;
         S.x_stride = (int64_t)ncols_pad;
@@ -1569,6 +1595,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     HIP_TRY(hipMemcpy(cs.sweeps.data(), d_sti + ncols, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cs.conv.data(), d_sti + 2 * (size_t)ncols, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cs.G.data(), d_stl, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
+    int64_t gram_rows = 0;  // item-space kernel: rows of G it read (its byte model)
+    if (use_gram)
+      for (int32_t c : requested) gram_rows += cs.G[(size_t)c];
     if (use_tile || use_gram)  // the Gram work of a column is the staging pass's cost figure
       for (int32_t c : requested) cs.G[(size_t)c] = m->h_cost[(size_t)c];
     HIP_TRY(hipMemcpy(cs.D.data(), d_stl + ncols, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
@@ -1675,6 +1704,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
                        : 8.0 * st.G + 12.0 * st.D + 4.0 * st.U + 8.0 * st.nnzW;
     st.gather_ms = now_ms() - t_kernel_done;
     st.gram_build_ms = use_gram ? m->G_build_ms : 0.0;
+    st.gram_rows = gram_rows;
+    st.gram_bytes = use_gram ? (double)gram_rows * 4.0 * (double)ncols_pad : 0.0;
     if (use_gram) m->G_build_ms = 0.0;  // (charged to the solve that paid for it)
     if (!opt.build_G) m->last_order = requested;
     st.total_ms = now_ms() - t_begin;
