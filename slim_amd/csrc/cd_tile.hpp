@@ -76,6 +76,14 @@
 
 namespace slimamd {
 
+// The chunks of a column slice are aligned to its END: the first chunk is the short one, the last
+// two -- the ones that stay in registers for the update -- are full.  (Aligned to the start, a
+// slice of 2.5 chunks kept 1.5 chunks and gathered 1 again on an updating visit; now it keeps 2
+// and gathers 0.5 again.)  0 restores the start-aligned grid (A/B builds).
+#ifndef SLIM_TILE_END_ALIGNED
+#define SLIM_TILE_END_ALIGNED 1
+#endif
+
 constexpr int kTileNW = 16;  // wavefronts per workgroup (default geometry)
 constexpr int kTileKMax = 32;  // largest cluster (workgroups sharing one tile)
 constexpr float kInactive = -__builtin_huge_valf();
@@ -659,7 +667,28 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         int id[NR];
         float v[NR];
         float r[STEPS];
-        int nh, nhv;  // valid nnz of the block the ids / the values belong to
+        // entries [lo, nh) of the block lie inside the slice (ids) / [lov, nhv) (values)
+        int nh, nhv, lo, lov;
+      };
+      // entries of a 64-nnz block starting at b0 that lie inside [s, e): [lo, nh)
+      auto span_of = [&](const int64_t b0, int& lo, int& nh) {
+        const int64_t left = e - b0, under = s - b0;
+        nh = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+        lo = under <= 0 ? 0 : (under < 64 ? (int)under : 64);
+      };
+      // uniform base + lane offset of entry `ent`, clamped into the slice (a block that misses the
+      // slice altogether reads one valid element of the array)
+      auto base_of = [&](const int64_t b0, const int lo, const int nh) -> int64_t {
+        if (nh > lo) return b0;
+        return b0 < 0 ? 0 : (b0 < S.nnz_last ? b0 : S.nnz_last);
+      };
+      auto off_of = [&](const int ent, const int lo, const int nh) -> uint32_t {
+        if (nh <= lo) return 0u;
+        const int c = ent < lo ? lo : (ent < nh ? ent : nh - 1);
+        return (uint32_t)c;
+      };
+      auto inside = [&](const int ent, const int lo, const int nh) -> bool {
+        return (uint32_t)(ent - lo) < (uint32_t)(nh - lo);  // (nh <= lo: never)
       };
       Blk A, B;
       // this wavefront's 64 consecutive nnz of chunk c0: one coalesced request per array and
@@ -670,39 +699,33 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       // once its gathers are issued, its values only after it has been summed)
       auto load_idx = [&](Blk& b, const int64_t c0) {
         const int64_t b0 = c0 + 64 * wave;
-        const int64_t left = e - b0;
-        b.nh = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+        span_of(b0, b.lo, b.nh);
         // unconditional loads of the raw entries (a load under a condition makes the number
         // of requests in flight path-dependent, and the compiler then waits for ALL of them
-        // where it only needs the oldest): uniform base, clamped into the array, + 32-bit
-        // lane offset; gather() turns them into line numbers when it needs them
-        const int64_t b0c = b0 < S.nnz_last ? b0 : S.nnz_last;
-        const int32_t* __restrict__ cb = ci + b0c;
+        // where it only needs the oldest): uniform base + 32-bit lane offset, clamped into the
+        // slice; gather() turns them into line numbers when it needs them
+        const int32_t* __restrict__ cb = ci + base_of(b0, b.lo, b.nh);
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-          const int ent = ent0 + 16 * k;
-          const uint32_t ec = (uint32_t)(ent < b.nh ? ent : 0);
+          const uint32_t ec = off_of(ent0 + 16 * k, b.lo, b.nh);
           b.id[k] = cb[ec];  // (raw user id: no arithmetic on it here, that would wait)
         }
       };
       auto load_val = [&](Blk& b, const int64_t c0) {  // after load_idx of the same block
         const int64_t b0 = c0 + 64 * wave;
-        const int64_t left = e - b0;
-        b.nhv = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
-        const int64_t b0c = b0 < S.nnz_last ? b0 : S.nnz_last;
-        const float* __restrict__ vb = cv + b0c;
+        span_of(b0, b.lov, b.nhv);
+        const float* __restrict__ vb = cv + base_of(b0, b.lov, b.nhv);
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-          const int ent = ent0 + 16 * k;
-          const uint32_t ec = (uint32_t)(ent < b.nhv ? ent : 0);
+          const uint32_t ec = off_of(ent0 + 16 * k, b.lov, b.nhv);
           b.v[k] = HAS_VAL ? vb[ec] : 1.0f;
         }
       };
       auto load_ids = [&](Blk& b, const int64_t c0) {
         if (HI && c0 == pf_here) {  // requested during the previous visit
-          const int64_t left = e - (c0 + 64 * wave);
-          b.nh = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+          span_of(c0 + 64 * wave, b.lo, b.nh);
           b.nhv = b.nh;
+          b.lov = b.lo;
 #pragma unroll
           for (int k = 0; k < NR; ++k) {
             b.id[k] = pf_id[k];
@@ -717,17 +740,20 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       // values of the entries past the slice are 0 (idempotent)
       auto mask_val = [&](Blk& b) {
 #pragma unroll
-        for (int k = 0; k < NR; ++k) b.v[k] = ent0 + 16 * k < b.nhv ? b.v[k] : 0.0f;
+        for (int k = 0; k < NR; ++k) b.v[k] = inside(ent0 + 16 * k, b.lov, b.nhv) ? b.v[k] : 0.0f;
       };
       // raw user ids -> line numbers; entries past the slice -> the spare line (binary
       // matrices: the values are 1 for the entries of the slice)
       auto fix_ids = [&](Blk& b) {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-          b.id[k] = ent0 + 16 * k < b.nh ? b.id[k] - ubase : udummy;
+          b.id[k] = inside(ent0 + 16 * k, b.lo, b.nh) ? b.id[k] - ubase : udummy;
           if (!HAS_VAL) b.v[k] = 1.0f;
         }
-        if (!HAS_VAL) b.nhv = b.nh;
+        if (!HAS_VAL) {
+          b.nhv = b.nh;
+          b.lov = b.lo;
+        }
       };
       // gather the residual lines of the block: STEPS loads per lane in flight
       auto gather = [&](Blk& b) {
@@ -785,15 +811,18 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 
       const uint64_t p0 = tick();
       float acc = 0.0f;
-      int64_t c0 = s;
       // The chunks of the slice alternate between the two blocks so that the last one lands in
       // A (it stays in registers for the update): with an even number of chunks the first one
       // is consumed on its own, the others pairwise -- the gathers of chunk k+1 are in flight
       // before chunk k is summed.
       const int64_t nchunks = e > s ? (e - s + CH - 1) / CH : 1;
-      // a wavefront beyond the end of a one-chunk slice has nothing to do (one branch around
-      // the whole stream; inside it every load is unconditional)
-      const bool mine = s + 64 * wave < e;
+      // the chunk grid: [sg, e) in nchunks chunks of CH (end-aligned: sg <= s, the first chunk
+      // holds the slice's remainder)
+      const int64_t sg = SLIM_TILE_END_ALIGNED ? e - nchunks * CH : s;
+      int64_t c0 = sg;
+      // a wavefront whose block of a one-chunk slice misses the slice has nothing to do (one
+      // branch around the whole stream; inside it every load is unconditional)
+      const bool mine = nchunks > 1 || (sg + 64 * wave < e && sg + 64 * wave + 64 > s);
       if (mine && HAS_VAL) {
         // valued matrices: one block at a time (the values of two blocks on top of their
         // residual lines do not fit the register budget: measured as 40 spills in this loop)
@@ -848,14 +877,17 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       if (HI) {
         const int64_t sn = uni(sn_v);
         const int nn = uni(nn_v);
+        // (the first chunk of the next visit's grid)
+        const int64_t sgn = SLIM_TILE_END_ALIGNED ? sn + nn - ((nn + CH - 1) / CH) * CH : sn;
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-          int64_t jj = sn + 64 * wave + ent0 + 16 * k;
+          int64_t jj = sgn + 64 * wave + ent0 + 16 * k;
           jj = jj < S.nnz_last ? jj : S.nnz_last;
+          jj = jj < 0 ? 0 : jj;
           pf_id[k] = ci[jj];
           pf_v[k] = HAS_VAL ? cv[jj] : 1.0f;
         }
-        pf_at = (nn > 0 && S.hi_prefetch) ? sn : -1;
+        pf_at = (nn > 0 && S.hi_prefetch) ? sgn : -1;
       }
       const uint64_t p1 = tick();
 
@@ -905,9 +937,9 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         }
         // the ids of the next chunk are requested before the lines of the current one are
         // waited for
-        if (s < stop) {
-          load_ids(A, s);
-          for (int64_t c = s; c < stop; c += CH) {
+        if (sg < stop) {
+          load_ids(A, sg);
+          for (int64_t c = sg; c < stop; c += CH) {
             gather(A);
             if (c + CH < stop) load_ids(B, c + CH);
             scatter(A, d);
@@ -919,6 +951,8 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
               }
               A.nh = B.nh;
               A.nhv = B.nhv;
+              A.lo = B.lo;
+              A.lov = B.lov;
             }
           }
         }

@@ -924,8 +924,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       use_gram = true;
     } else if (kernel == SLIMGPU_KERNEL_AUTO && gram_fits && lds_need > 64 * 1024 &&
                !std::getenv("SLIM_GPU_NO_GRAMCD")) {
-      bool repeated = m->G_ready || m->expect_solves >= 2 ||
-                      (!m->last_order.empty() && m->last_order == order);
+      // (G serves every column and costs a screen pass over all of them: not for a grid over a
+      // small part of the matrix unless it is there already)
+      bool repeated = m->G_ready ||
+                      ((int64_t)nwork * 4 >= ncols &&
+                       (m->expect_solves >= 2 || (!m->last_order.empty() && m->last_order == order)));
       // SLIM_GPU_GRAMCD=first: also for a FIRST solve when the byte model says item space wins --
       // most columns requested (G serves every column; building it costs about one tenth of a
       // residual sweep) and columns long against the item count (an update moves 4 ncols bytes

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 namespace slimamd {
 
@@ -80,15 +81,58 @@ void csr_build_index(slim_csr_t* m, int what) {
   int32_t* di = xmalloc<int32_t>(nnz);
   float* dv = sv ? xmalloc<float>(nnz) : nullptr;
   std::fill(dp, dp + ndst + 1, 0);
-  for (int64_t k = 0; k < nnz; ++k) ++dp[si[k] + 1];
-  std::partial_sum(dp, dp + ndst + 1, dp);
-  std::vector<ssize_t> fill(dp, dp + ndst);
-  for (int32_t s = 0; s < nsrc; ++s)
-    for (ssize_t k = sp[s]; k < sp[s + 1]; ++k) {
-      const ssize_t slot = fill[si[k]]++;
-      di[slot] = s;
-      if (dv) dv[slot] = sv[k];
+  // Large models (a C5 grid step returns 77M entries 45 times over): the counting-sort transpose
+  // on several host threads -- sources cut into T ranges of equal nnz, one histogram per range,
+  // every range scatters from its own start offsets.  Within a destination row the sources stay
+  // ascending (ranges ascending, each walked in order): the same arrays as the serial form.
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int T = nnz >= (int64_t(1) << 22) ? (int)std::min<unsigned>(16u, std::max(1u, hw)) : 1;
+  if (T > 1) {
+    std::vector<int32_t> cut((size_t)T + 1, nsrc);
+    cut[0] = 0;
+    for (int t = 1; t < T; ++t)
+      cut[(size_t)t] = (int32_t)(std::lower_bound(sp, sp + nsrc + 1, (ssize_t)(nnz / T * t)) - sp);
+    std::vector<std::vector<ssize_t>> hist((size_t)T, std::vector<ssize_t>((size_t)ndst, 0));
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        ssize_t* h = hist[(size_t)t].data();
+        for (ssize_t k = sp[cut[(size_t)t]]; k < sp[cut[(size_t)t + 1]]; ++k) ++h[si[k]];
+      });
+    for (auto& x : th) x.join();
+    th.clear();
+    ssize_t run = 0;
+    for (int32_t d = 0; d < ndst; ++d) {  // hist[t][d] becomes range t's first slot in row d
+      dp[d] = run;
+      for (int t = 0; t < T; ++t) {
+        const ssize_t c = hist[(size_t)t][(size_t)d];
+        hist[(size_t)t][(size_t)d] = run;
+        run += c;
+      }
     }
+    dp[ndst] = run;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        ssize_t* fill = hist[(size_t)t].data();
+        for (int32_t s = cut[(size_t)t]; s < cut[(size_t)t + 1]; ++s)
+          for (ssize_t k = sp[s]; k < sp[s + 1]; ++k) {
+            const ssize_t slot = fill[si[k]]++;
+            di[slot] = s;
+            if (dv) dv[slot] = sv[k];
+          }
+      });
+    for (auto& x : th) x.join();
+  } else {
+    for (int64_t k = 0; k < nnz; ++k) ++dp[si[k] + 1];
+    std::partial_sum(dp, dp + ndst + 1, dp);
+    std::vector<ssize_t> fill(dp, dp + ndst);
+    for (int32_t s = 0; s < nsrc; ++s)
+      for (ssize_t k = sp[s]; k < sp[s + 1]; ++k) {
+        const ssize_t slot = fill[si[k]]++;
+        di[slot] = s;
+        if (dv) dv[slot] = sv[k];
+      }
+  }
   if (what == 0) {
     std::free(m->colptr); std::free(m->colind); std::free(m->colval);
     m->colptr = dp; m->colind = di; m->colval = dv;

@@ -366,3 +366,47 @@ def test_bench_plain_command_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
     assert out["ranks"]["world"] == 2 and len(out["ranks"]["kernel_ms_per_rank"]) == 2
     assert all(v > 0 for v in out["ranks"]["kernel_ms_per_rank"])
+
+
+@pytest.mark.timeout(900, method="thread")
+def test_bench_four_ranks_whole_matrix_extras():
+    """The N >= 4 branch of bench.py as the driver will run it at N = 4 / 8, on a 1/50-scale C4
+    (20 000 x 2 000): after the timed steps one step over ALL item columns sharded over the ranks
+    (`strong_whole_matrix`) and the same step in item space (`item_space`: every rank builds
+    G = R^T R, then solves its shard) -- both agreed on by all ranks before any collective, so a
+    failure in an extra step costs its key, not the line.  On a one-GPU box the four ranks share
+    the device over gloo (clusters of 1: co-residency across processes is not a given there)."""
+    import json
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 4 else "gloo"
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1",
+           "--workload", "c4", "--scale", "0.02", "--batch", "256", "--cluster", "1",
+           "--backend", backend, "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["value"] > 0 and len(out["ranks"]["kernel_ms_per_rank"]) == 4
+    sw = out["strong_whole_matrix"]
+    assert sw["columns"] == 2000 and sw["seconds"] > 0 and sw["kernel"] == "tile32", sw
+    assert sw["item_space"]["kernel"] == "gram" and sw["item_space"]["seconds"] > 0, sw
+
+
+@pytest.mark.timeout(600, method="thread")
+def test_bench_dry_run_of_an_eight_rank_step():
+    """what eight ranks would each get in a step, measured on one device with
+    no collective (bench.py --dry-run-world 8): the eight interleaved shards of a step's range
+    solved one after the other -- kernel times within a few percent of each other, and the
+    projected length of the driver's command reported against its limit.  (Scaled-down matrix
+    here; the full-size figure is profiles/r04/dry_run_world8.json.)"""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-world", "8", "--workload", "c4",
+           "--scale", "0.05", "--batch", "512", "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=550, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["dry_run_world"] == 8 and len(out["ranks"]) == 8
+    assert all(x["columns"] == 512 and x["kernel_ms"] > 0 for x in out["ranks"])
+    assert out["kernel_ms_spread"] < 0.25          # (tiny shards: 16 tiles each; full size: < 5 %)
+    assert out["projected_command_s"]["total"] > 0
