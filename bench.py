@@ -471,11 +471,19 @@ def item_space_grid(args, dev, npairs=3):
         del rowptr, rowind
         torch.cuda.empty_cache()
         warm = [r["seconds"] for r in recs[1:]]
+        last = recs[-1]
+        model_gbps = last["row_GBps"]
         return {"workload": "c5 (synthetic %dx%d, ~1e9 nnz, binary), first %d pairs of test/l12file, "
                             "all %d item columns per pair, warm start" % (nrows, ncols, npairs, ncols),
                 "pairs": recs, "seconds": round(total, 2),
                 "value": npairs * ncols / total, "unit": "item-columns/s",
                 "warm_pair_s": round(sum(warm) / len(warm), 2) if warm else None,
+                "roofline": {"bound": "hbm", "achieved": model_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": model_gbps / HBM_PEAK_GBS, "traffic": None,
+                             "note": "the last pair's launch of cd_gram_kernel: rows_of_G_read x 4 x ncols "
+                                     "bytes over its HIP-event time; PMC passes of the same launches: "
+                                     "profiles/r04/gram_c5_pmc_summary.txt (7.3 TB/s between L2 and the "
+                                     "fabric, Infinity-Cache hits included)"},
                 "byte_model": "rows_of_G_read x 4 x ncols bytes per solve (one row of G per update and "
                               "per folded warm-start coefficient; g stays in LDS): row_GBps = that over "
                               "the kernel time -- above the 8 TB/s of HBM means rows shared by the "
