@@ -375,7 +375,8 @@ def main():
         if world == 1:
             out["parity"] = ml100k_parity(dev.index)
         if world == 1 and args.workload == "c4" and args.scale == 1 and args.kernel != 5 \
-                and not args.no_item_space and WALL_BUDGET_S - (time.time() - T_START) > 560:
+                and not args.no_item_space and WALL_BUDGET_S - (time.time() - T_START) > 620:
+            out["item_space_step"] = item_space_step(mat, last_b, span, opts, W)
             out["item_space_grid"] = item_space_grid(args, dev)
         if world == 1 and args.cpu_seconds > 0 and args.workload != "ml100k":
             out["cpu_baseline"] = cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols,
@@ -424,6 +425,33 @@ def dry_run(args, mat, ncols, per_gpu, opts, nnz):
                                     "whole_matrix_step_runs": bool(total < WALL_BUDGET_S)},
             "note": "one device, ranks solved one after the other: no RCCL, no peer copies -- what "
                     "is measured is the evenness of the shards and the step time they imply"}
+
+
+def item_space_step(mat, b, span, opts, W_res):
+    """Secondary figure, under its own key: the LAST timed step once more -- the same columns of
+    the same matrix, from scratch -- in item space (cd_gram.hpp): G = R^T R of the whole matrix is
+    built inside the measured time and nothing is carried in.  Also a parity figure: the two
+    kernels walk the same visiting order, so their models differ by fp32 rounding only."""
+    import scipy.sparse as sp
+    saved = {k: os.environ.pop(k, None) for k in ("SLIM_GPU_NO_GRAM", "SLIM_GPU_NO_GRAMCD")}
+    try:
+        t0 = time.perf_counter()
+        Wi, st = mat.learn(col_begin=b, col_end=b + span, **dict(opts, kernel=5))
+        dt = time.perf_counter() - t0
+        d = abs(sp.csc_matrix(Wi) - sp.csc_matrix(W_res))
+        return {"columns": int(span), "seconds": round(dt, 2), "value": span / dt, "unit": "item-columns/s",
+                "G_build_s": round(st["gram_build_ms"] * 1e-3, 2), "kernel_s": round(st["kernel_ms"] * 1e-3, 2),
+                "rows_of_G_read": int(st["gram_rows"]), "kernel": KERNEL_NAMES.get(st["kernel"], st["kernel"]),
+                "max_abs_dW_vs_the_timed_step": float(d.max()) if d.nnz else 0.0,
+                "nnzW": int(st["nnzW"]),
+                "note": "the columns of the last timed step, from scratch, G = R^T R (all 100 000 items) built "
+                        "inside `seconds`; not `value`: SURVEY.md 8(d) prices the residual kernel's traffic"}
+    except Exception as e:   # noqa: BLE001 -- an extra must not cost the line
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
 
 
 def item_space_grid(args, dev, npairs=3):
