@@ -669,7 +669,18 @@ def test_edge_cases():
     Z = sp.csr_matrix((4, 3), dtype=np.float32)
     mz = DeviceMatrix.from_scipy(Z)
     assert mz.learn()[0].nnz == 0
+    assert mz.learn(kernel=KERNEL_GRAM)[0].nnz == 0
     mz.close()
+    # the same corner cases in item space and on the tile kernel (tile order), incl. an empty range
+    m = DeviceMatrix.from_scipy(R)
+    for kernel in (KERNEL_GRAM, KERNEL_TILE):
+        for kw in (dict(), dict(niters=1), dict(l1r=0.0, l2r=0.1), dict(l1r=100.0)):
+            W, st = m.learn(seed=1, kernel=kernel, **kw)
+            Wo = O.learn_cd_tile(R, tileP=32, seed=1, l1r=kw.get("l1r", 1.0), l2r=kw.get("l2r", 1.0),
+                                 maxniters=kw.get("niters", 10000))
+            assert st["kernel"] == kernel and W.shape == (6, 6) and maxdiff(W, Wo) <= 1e-5
+        assert m.learn(kernel=kernel, col_begin=2, col_end=2)[0].nnz == 0
+    m.close()
 
 
 # ---- top-N prediction on the GPU ---------------------------------------------
