@@ -679,7 +679,9 @@ def cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols, b, span, opts,
     parts, t, round_rates, D_full = [], 0.0, [], {}
     done_rounds = 0
     for k in range(rounds):
-        if k >= 2 and left() < 330 + 1.3 * (t / k):   # keep room for the checks and the other modes
+        # (room is kept for the parity checks and the faithful 32-thread round, ~65 s; the
+        # all-core modes come last and shrink or drop out by themselves)
+        if k >= 2 and left() < 90 + 1.3 * (t / k):
             break
         cols_k = pool[k * use:(k + 1) * use]
         Wk, tk, stk = timed(cols_k, use, gram)

@@ -360,7 +360,9 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
             }
           }
           if (any_upd) {  // one pass over g for all the rows of the batch, in visiting order
-            constexpr int CS = 4;
+            // (CS float4 of a row in flight per thread: with 8 wavefronts per CU, 4 of them are
+            // 32 KB per CU -- by Little's law ~4 TB/s over the chip, which is what it measured)
+            constexpr int CS = NW == 8 ? 8 : 4;
             for (int c0 = tid; c0 < n4; c0 += CS * NT) {
               float4 gv[CS];
 #pragma unroll
