@@ -242,3 +242,27 @@ def test_unsupported_algorithms_are_input_errors(ml100k):
                        io.ctypes.data_as(C.c_void_p), None, None, C.byref(st))
     assert not h and st.value == -2
     assert "unknown algorithm" in _lib.last_error()
+
+
+def test_large_model_row_view_is_built_on_several_threads():
+    """A model of more than 4M entries takes the threaded counting-sort transpose of
+    host_csr.cpp::csr_build_index (a C5 grid step returns 77M entries, 45 times over): the row
+    view must be the one scipy builds -- same offsets, ids ascending inside every row, same values."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from slim_amd.engine import _scipy_to_model_handle, model_to_scipy
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    W = sp.random(3000, 3000, density=0.6, format="csr", random_state=rng, dtype=np.float32)
+    W.sort_indices()
+    h = _scipy_to_model_handle(lib, W)
+    view = C.cast(h, C.POINTER(_lib.CsrView)).contents
+    n = int(view.ncols)
+    rp = np.ctypeslib.as_array(view.rowptr, shape=(n + 1,)).astype(np.int64)
+    nnz = int(rp[-1])
+    assert nnz == W.nnz > (1 << 22)
+    ri = np.ctypeslib.as_array(view.rowind, shape=(nnz,)).copy()
+    rv = np.ctypeslib.as_array(view.rowval, shape=(nnz,)).copy()
+    assert np.array_equal(rp, W.indptr) and np.array_equal(ri, W.indices) and np.array_equal(rv, W.data)
+    Wc = model_to_scipy(lib, h, free=True)
+    assert abs(Wc.tocsr() - W).max() == 0.0

@@ -122,3 +122,20 @@ def test_tile_walk_warm_start_reaches_the_per_item_warm_start(ml100k):
     sol = O.learn_cd_tile(R, seed=1, nthreads=8)
     _, s2, _, _ = O.learn_cd_tile(R, seed=1, nthreads=8, imodel=sol, return_stats=True)
     assert s2["sweeps"].mean() <= 1.01
+
+
+def test_time_budget_cuts_columns_off_and_reports_what_they_reached(ml100k):
+    """bench.py's bounded all-cores sample (oracle_set_time_budget): past the budget no new sweep
+    starts; a column cut off reports conv = -1 and the D it reached, a column never started
+    conv = -2; the budget applies to ONE call."""
+    R, _ = ml100k
+    W, st, _, _ = O.learn_cd(R, order=O.ORDER_LOCAL, aty=O.ATY_GRAM, nthreads=2, return_stats=True, chunk=1)
+    full = O.learn_seconds()
+    assert (st["conv"] >= 0).all()
+    O.set_time_budget(full / 4)
+    _, st2, _, _ = O.learn_cd(R, order=O.ORDER_LOCAL, aty=O.ATY_GRAM, nthreads=2, return_stats=True, chunk=1)
+    assert O.learn_seconds() < 0.8 * full
+    assert (st2["conv"] == -2).sum() > 100 and (st2["conv"] >= 0).sum() > 50
+    assert 0 < st2["D"].sum() < st["D"].sum()
+    _, st3, _, _ = O.learn_cd(R, order=O.ORDER_LOCAL, aty=O.ATY_GRAM, nthreads=2, return_stats=True, chunk=1)
+    assert (st3["conv"] >= 0).all() and abs(st3["D"].sum() - st["D"].sum()) <= 0.01 * st["D"].sum()
