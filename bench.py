@@ -22,6 +22,14 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
                 events on the engine's stream, against the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (a port of the reference's OpenMP CD path; the reference
                 itself cannot be built here) timed on a bounded sample of the same columns
+and, at N = 1 on the default workload, two secondary figures under their own keys (never
+`value`; SURVEY.md 8(d)'s formula does not price them):
+  item_space_step  the last timed step once more, from scratch, in item space (cd_gram.hpp;
+                   G = R^T R built inside the measured time), with the difference of the models
+  item_space_grid  the first pairs of the C5 model-selection grid (BASELINE.json configs[4])
+                   on the path the engine takes for a grid
+The command budgets itself against the driver's 1800 s (SLIM_BENCH_WALL_BUDGET): the extras
+and the CPU leg shrink or drop out, with a note, rather than overrun.
 """
 import argparse
 import json
