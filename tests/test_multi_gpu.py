@@ -17,7 +17,7 @@ import scipy.sparse as sp
 from conftest import GOLDEN, ROOT
 from slim_amd import _lib
 from slim_amd.constants import SLIM_NOPTIONS, Opt
-from slim_amd.engine import KERNEL_TILE, KERNEL_WAVE_LDS, DeviceMatrix, model_to_scipy
+from slim_amd.engine import KERNEL_GRAM, KERNEL_TILE, KERNEL_WAVE_LDS, DeviceMatrix, model_to_scipy
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +48,7 @@ def _slim_learn(R, ngpus=None, dbglvl=0, **dopts):
     return model_to_scipy(lib, h), st.value, stats.as_dict()
 
 
-@pytest.mark.parametrize("kernel,geom", [(KERNEL_WAVE_LDS, {}), (KERNEL_TILE, {"cluster": 2})])
+@pytest.mark.parametrize("kernel,geom", [(KERNEL_WAVE_LDS, {}), (KERNEL_TILE, {"cluster": 2}), (KERNEL_GRAM, {})])
 def test_shards_do_not_change_a_column(ml100k, kernel, geom):
     """Shard i of c = granules i, i + c, ... of the cost-ordered work list, visiting order keyed
     by the tile's position in the unsharded list: the union of the shards IS the single solve."""
@@ -89,6 +89,39 @@ def test_slim_learn_over_two_shards_equals_one_gpu(ml100k, monkeypatch):
     monkeypatch.setenv("SLIM_GPU_NGPUS", "2")
     W3, st3, _ = _slim_learn(R, L1R=1.0, L2R=1.0)
     assert st3 == 1 and maxdiff(W1, W3) == 0.0
+
+
+def test_slim_learn_item_space_over_two_replicas(monkeypatch):
+    """The in-library team on the item-space path: SLIM_Learn with ngpus = 2 and option slot 15 =
+    SLIMGPU_KERNEL_GRAM -- every replica of R builds its own G = R^T R and solves its shard --
+    returns the ngpus = 1 model bit for bit (a column's walk does not depend on the shards)."""
+    rng = np.random.default_rng(5)
+    R = sp.random(40000, 3000, density=0.004, format="csr", random_state=rng, dtype=np.float32)
+    R.data = rng.integers(1, 6, R.nnz).astype(np.float32)
+    R.sort_indices()
+    lib = _lib.load()
+
+    def learn(ngpus):
+        io = np.full(SLIM_NOPTIONS, -1, np.int32)
+        do = np.full(SLIM_NOPTIONS, -1.0, np.float64)
+        io[Opt.GPU_KERNEL] = KERNEL_GRAM
+        io[Opt.GPU_NGPUS] = ngpus
+        do[Opt.L1R], do[Opt.L2R] = 1.0, 0.5
+        st = C.c_int32(0)
+        h = lib.SLIM_Learn(R.shape[0], R.indptr.astype(np.intp), R.indices.astype(np.int32),
+                           R.data.astype(np.float32).ctypes.data_as(C.c_void_p),
+                           io.ctypes.data_as(C.c_void_p), do.ctypes.data_as(C.c_void_p), None, C.byref(st))
+        assert h, _lib.last_error()
+        stats = _lib.Stats()
+        lib.SLIMGPU_LastStats(C.byref(stats))
+        return model_to_scipy(lib, h), stats.as_dict()
+
+    W1, s1 = learn(1)
+    assert s1["kernel"] == KERNEL_GRAM and W1.nnz > 100000
+    if lib.SLIMGPU_DeviceCount() < 2:
+        monkeypatch.setenv("SLIM_GPU_DEVICES", "0,0")
+    W2, s2 = learn(2)
+    assert s2["kernel"] == KERNEL_GRAM and W2.nnz == W1.nnz and maxdiff(W1, W2) == 0.0
 
 
 def test_slim_learn_more_gpus_than_devices_is_an_input_error(ml100k, monkeypatch):
