@@ -310,8 +310,66 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       s_item[tid] = tid < nprob ? S.order[base + tid] : -1;
       s_na[tid] = 0;
     }
+    // -- G = R^T R of a binary matrix (S.gram_mode 3 with S.gram_bits): the y of the tile's P items
+    //    packed into ONE word per user of this member's range, in LDS (clusters of 32 on a
+    //    1M-user matrix: 31K users, 125 KB) -- a column's dot products with all P items are then
+    //    P ballots per 64 nnz over words read from LDS: no residual lines, no HBM gathers, only
+    //    the column ids are streamed (the line-gathering screen pass below spent 10 s on the 1e9
+    //    nnz of C4; this form is bound by the id stream)
+    const bool gbits = !HAS_VAL && S.gram_mode == 3 && S.gram_bits != 0;
+    if (gbits) {
+      const int nus = uend - ubase;
+      for (int k = tid; k < nus; k += NT) s_bits[k] = 0u;
+      __syncthreads();
+#pragma unroll
+      for (int pp = 0; pp < PPW; ++pp) {
+        const int pq = wave + pp * NW;
+        const int witem = s_item[pq];
+        if (witem >= 0) {
+          const int64_t cs = uni(csplit[(int64_t)witem * (K + 1) + mk]);
+          const int64_t ce = uni(csplit[(int64_t)witem * (K + 1) + mk + 1]);
+          for (int64_t j = cs + lane; j < ce; j += 64) atomicOr(&s_bits[ci[j] - ubase], 1u << pq);
+        }
+      }
+      __syncthreads();
+      // (slices are short here -- a column's nnz over 32 members -- so the slice bounds and the
+      // position of the NEXT column are requested while this one is counted)
+      int64_t cs_n = 0, ce_n = 0;
+      int pos_n = 0;
+      if (wave < ncols) {
+        cs_n = csplit[(int64_t)wave * (K + 1) + mk];
+        ce_n = csplit[(int64_t)wave * (K + 1) + mk + 1];
+        pos_n = S.gram_pos[wave];
+      }
+      for (int i = wave; i < ncols; i += NW) {
+        const int64_t cs = uni(cs_n), ce = uni(ce_n);
+        const int pos_i = uni(pos_n);
+        if (i + NW < ncols) {
+          cs_n = csplit[(int64_t)(i + NW) * (K + 1) + mk];
+          ce_n = csplit[(int64_t)(i + NW) * (K + 1) + mk + 1];
+          pos_n = S.gram_pos[i + NW];
+        }
+        if (pos_i < base) continue;  // (symmetric fill: see the screen pass)
+        int cnt[P];
+#pragma unroll
+        for (int qq = 0; qq < P; ++qq) cnt[qq] = 0;
+        for (int64_t jb = cs; jb < ce; jb += 64) {
+          const bool ok = jb + lane < ce;
+          uint32_t w = 0u;
+          if (ok) w = s_bits[ci[jb + lane] - ubase];
+          if (__ballot(w != 0u) == 0ull) continue;
+#pragma unroll
+          for (int qq = 0; qq < P; ++qq) cnt[qq] += __popcll(__ballot((w >> qq) & 1u));
+        }
+        float v = 0.0f;
+#pragma unroll
+        for (int qq = 0; qq < P; ++qq) v = lane == qq ? (float)cnt[qq] : v;
+        if (lane < P) part[(int64_t)i * P + lane] = v;  // one 128-byte line per column
+      }
+      cluster_barrier();  // every member's partial sums are published
+    }
     // -- clear the interleaved work vectors
-    {
+    if (!gbits) {
       // (x needs no clearing: the active-set pass below assigns every entry)
       float4* r4 = reinterpret_cast<float4*>(r);
       const int64_t nr4 = (int64_t)(uend - ubase + 1) * (P / 4);  // + the spare line (see visit)
@@ -329,7 +387,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 #pragma unroll
     for (int pp = 0; pp < PPW; ++pp) {
       const int pq = wave + pp * NW;
-      const int witem = s_item[pq];
+      const int witem = gbits ? -1 : s_item[pq];
       if (witem >= 0) {
         const int64_t cs = uni(csplit[(int64_t)witem * (K + 1) + mk]);
         const int64_t ce = uni(csplit[(int64_t)witem * (K + 1) + mk + 1]);
@@ -353,7 +411,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     //    Gram-column form, sum over the item's users of their rows, needs one device-scope
     //    float atomic per touched (item, problem): 1.2 s of a 12.9 s median tile on C4, 7 s of
     //    the 27 s heaviest tile.)
-    if (!cached) {
+    if (!cached && !gbits) {
       constexpr int GS = 8;  // gather steps in flight per lane (16: no gain, measured)
       for (int i = wave; i < ncols; i += NW) {
         // building G = R^T R (gram_mode 3): G is symmetric, so a tile only forms the sums of the
@@ -424,7 +482,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         if (slot == 0) part[(int64_t)i * P + q] = acc;  // one 128-byte line per column
       }
     }
-    if (!cached) cluster_barrier();  // every member's partial sums are published
+    if (!cached && !gbits) cluster_barrier();  // every member's partial sums are published
     else __syncthreads();
 
     // -- active sets: x = 0 for active, -inf for inactive
@@ -521,6 +579,24 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         }
         if (lane == 0) s_na[pq] = na;
       }
+    } else if (S.gram_mode == 3) {
+      // rows item_q of G and, for the columns of later tiles, their mirror entries (the tile of
+      // column i will skip this tile's columns); columns of earlier tiles were skipped.  The K
+      // partial sums of an entry are added by ONE member: the members share the entries
+      const int64_t n = (int64_t)ncols * P;
+      const int64_t per = (n + K - 1) / K;
+      const int64_t hi = (mk + 1) * per < n ? (mk + 1) * per : n;
+      for (int64_t idx = mk * per + tid; idx < hi; idx += NT) {
+        const int i = (int)(idx >> LOGP), qq = (int)(idx & (P - 1));
+        const int it = s_item[qq];
+        const int pi = S.gram_pos[i];
+        if (pi >= base && it >= 0) {
+          float a = 0.0f;  // members in rank order
+          for (int k = 0; k < K; ++k) a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
+          S.G[(int64_t)it * S.G_ld + i] = a;
+          if (pi >= base + P) S.G[(int64_t)i * S.G_ld + it] = a;
+        }
+      }
     } else {  // estimate.c:433-444: aTy > l1 (strict), the item itself excluded
       const int64_t n = (int64_t)ncols * P;
       for (int64_t idx = tid; idx < n; idx += NT) {
@@ -529,18 +605,6 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         float a = 0.0f;  // members in rank order: the same sum on every member
         if (cached) {
           a = gram_t[idx];
-        } else if (S.gram_mode == 3) {
-          // rows item_q of G and, for the columns of later tiles, their mirror entries (the tile
-          // of column i will skip this tile's columns); columns of earlier tiles were skipped
-          const int pi = S.gram_pos[i];
-          if (pi >= base && it >= 0) {
-            for (int k = 0; k < K; ++k)
-              a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
-            if (mk == 0) {
-              S.G[(int64_t)it * S.G_ld + i] = a;
-              if (pi >= base + P) S.G[(int64_t)i * S.G_ld + it] = a;
-            }
-          }
         } else {
           for (int k = 0; k < K; ++k)
             a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];

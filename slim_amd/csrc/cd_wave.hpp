@@ -115,6 +115,7 @@ struct SolveArgs {
   int64_t G_ld;
   int32_t* tile_nunion;
   const int32_t* gram_pos;       // gram_mode 3: position of every column in the work list
+  int32_t gram_bits;             // gram_mode 3, binary matrix: y packed one word per user in LDS
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;
   int64_t* out_off;

@@ -1014,6 +1014,19 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     // 256 tiles); with many tiles throughput matters and two small workgroups win (150 vs
     // ~141 col/s at 512 tiles).
     int tileNW = (nwork + tileP - 1) / tileP >= 2 * m->num_cus ? 8 : 16;
+    // G = R^T R of a binary matrix: clusters of 32 whose members keep the y of a tile's 32 items as
+    // one word per user of their range in LDS (cd_tile.hpp, gbits) -- when that range fits
+    int req_cluster = opt.cluster;
+    size_t gram_bits_lds = 0;
+    if (opt.build_G && use_tile && tileP == 32 && m->binary && !std::getenv("SLIM_GPU_NO_GBITS")) {
+      ensure_cluster_split(m, 5);
+      const size_t need = sizeof(uint32_t) * (size_t)(round_up(m->max_range_rows[5], 64) + 64);
+      if (need <= 148 * 1024 && m->num_cus >= 32) {
+        gram_bits_lds = need;
+        req_cluster = 32;
+        tileNW = 16;
+      }
+    }
     // (four 4-wavefront workgroups per CU were measured too: no gain, even on columns of ~900 nnz)
     if (const char* e = std::getenv("SLIM_GPU_TILE_NW")) tileNW = std::atoi(e) == 16 ? 16 : 8;
     // warm start (estimate.c:453-464) on the tile path: how the previous coefficients are folded
@@ -1068,7 +1081,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int wg_slots = m->num_cus * (16 / tileNW);
     if (use_tile) {
       int per_cu = 0;
-      const size_t worst_lds = kBitmapBytes;
+      const size_t worst_lds = std::max<size_t>(kBitmapBytes, gram_bits_lds);
       // (static + dynamic LDS beyond 64 KB needs the attribute)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)worst_lds));
@@ -1082,7 +1095,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     }
     // force_k1: no clusters, no heavy phase -- the geometry that needs no co-residency at all
     // (fallback after a cluster timed out waiting for a member, e.g. under a CU mask)
+    bool force_k1_now = false;
     auto plan_tiles = [&](const bool force_k1) {
+      force_k1_now = force_k1;
       clusterK = 1; cluster_lg = 0; nclusters = 0;
       clusterHi = 0; hi_lg = 0; nheavy = 0; nclusters_hi = 0; auto_heavy = 0;
       const int ngroups_all = (nwork + tileP - 1) / tileP;
@@ -1090,9 +1105,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       // every CU busy behind the slowest one (auto), or as requested
       if (force_k1) {
         clusterK = 1;
-      } else if (opt.cluster == 1 || opt.cluster == 2 || opt.cluster == 4 || opt.cluster == 8 ||
-                 opt.cluster == 16 || opt.cluster == 32) {
-        clusterK = opt.cluster;
+      } else if (req_cluster == 1 || req_cluster == 2 || req_cluster == 4 || req_cluster == 8 ||
+                 req_cluster == 16 || req_cluster == 32) {
+        clusterK = req_cluster;
       } else {
         // the heaviest tile runs ~7x the median (popular items need more sweeps): a
         // cluster should see >= ~8 tiles so the others fill in behind it; with fewer
@@ -1203,6 +1218,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       // (the bitmap follows the member's user range, which grows when the fallback below
       // re-plans without clusters: the launch size must follow it)
       tile_lds = sizeof(uint32_t) * (size_t)bm_words;
+      if (gram_bits_lds && clusterK == 32 && !force_k1_now) {  // one word per user of a member's range
+        bm_shift = 0;
+        bm_words = (int)(gram_bits_lds / sizeof(uint32_t));
+        tile_lds = gram_bits_lds;
+      }
     };
     int32_t* d_nunion = nullptr;
     if (use_gram) {
@@ -1379,6 +1399,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.G_ld = m->G_ld;
       S.tile_nunion = d_nunion;
       S.gram_pos = nullptr;
+      S.gram_bits = (gram_bits_lds && clusterK == 32 && tile_lds == gram_bits_lds) ? 1 : 0;
       if (opt.build_G) {
         if (attempt > 0 || cluster_fallback || npend != ncols) {
           // (the symmetric fill needs every column in ONE launch; a re-plan after a cluster
