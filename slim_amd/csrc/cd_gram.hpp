@@ -19,7 +19,8 @@
 // up to fp32 rounding and the oracle's tile walk checks it visit for visit.  What it needs is G:
 // ncols^2 floats (C5, 20K items: 1.6 GB), exact in fp32 for binary R (co-rating counts), built
 // once per matrix by the tile kernel's screen pass (S.gram_mode 3: a_i . y for every column i
-// and every item of a tile IS a block of 32 rows of G) -- worth it whenever most columns of a
+// and every item of a tile IS a block of 32 rows of G; symmetric fill; for a binary matrix of up
+// to ~1.2M users with y packed one word per user in LDS) -- worth it whenever most columns of a
 // matrix are solved, and paid once for a model-selection grid (slim_mselect.c:94-113: 45
 // (l1, l2) pairs over one R, each warm-started from the previous model).  The active set
 // {i != iC : aTy_i > l1} (estimate.c:433-444) is read off row iC; a warm start folds the previous
