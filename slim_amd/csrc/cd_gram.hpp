@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void gram_union_kernel(const DevMatrix A, const
 // read and rewritten on every update: 12 ncols bytes per update instead of 4, most of it served
 // by the Infinity Cache), every thread walks its float4 slices in a loop.
 template <int NW, int V>
-__global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, const SolveArgs S) {
+__global__ __launch_bounds__(64 * NW, (V == 0 && NW == 8) ? 4 : 1) void cd_gram_kernel(const DevMatrix A, const SolveArgs S) {
   constexpr int NT = 64 * NW;
   constexpr bool LDSG = V > 0;
   constexpr int VV = LDSG ? V : 1;  // (array bounds of the LDS form)
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
         // from single elements of the rows (below); when the batch is decided, every thread
         // applies all of its rows to its slices of g in ONE pass -- g is read and written once per
         // batch, the rows once each, their loads independent of one another.
-        constexpr int MS = NW == 8 ? 16 : 8;  // (8 wavefronts per workgroup: 256 VGPRs each)
+        constexpr int MS = 8;  // (8 slots per lane keep the kernel at 128 VGPRs: two workgroups per CU)
         for (int p0 = 0; p0 < nunion; p0 += 64 * MS) {
           __syncthreads();  // the previous batch's pass over g is complete
           int i[MS], len[MS];
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64 * NW) void cd_gram_kernel(const DevMatrix A, con
           if (any_upd) {  // one pass over g for all the rows of the batch, in visiting order
             // (CS float4 of a row in flight per thread: with 8 wavefronts per CU, 4 of them are
             // 32 KB per CU -- by Little's law ~4 TB/s over the chip, which is what it measured)
-            constexpr int CS = NW == 8 ? 8 : 4;
+            constexpr int CS = 4;
             for (int c0 = tid; c0 < n4; c0 += CS * NT) {
               float4 gv[CS];
 #pragma unroll

@@ -5,7 +5,9 @@ namespace slimamd {
 bool gram_geometry(int ncols_pad, int* nw, int* v) {
   const int n4 = ncols_pad / 4;
   if (ncols_pad > kGramMaxColsPad) {  // g in HBM (cd_gram.hpp, V = 0)
-    *nw = 8;  // (16 slots per lane and 256 VGPRs: 152 s against 158.5 s on the whole C4 matrix)
+    *nw = 8;  // (two 8-wavefront workgroups per CU, 8 visit slots per lane: the whole C4 matrix in
+              // 125 s of kernel against 137-146 s with one workgroup of 16 slots and 144 s with four
+              // 4-wavefront workgroups)
     *v = 0;
     return true;
   }
