@@ -933,7 +933,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       // most columns requested (G serves every column; building it costs about one tenth of a
       // residual sweep) and columns long against the item count (an update moves 4 ncols bytes
       // there, ~128 nnz(col) bytes for one changed problem of a tile here).  Measured: C5 cold
-      // 158 -> 10 s, C4 whole matrix 579 -> 152 s; C4 at 0.1 % density stays with the tile kernel.
+      // 158 -> 10 s, C4 whole matrix 579 -> 133 s; C4 at 0.1 % density stays with the tile kernel.
       if (const char* e = std::getenv("SLIM_GPU_GRAMCD"); e && std::strcmp(e, "first") == 0)
         repeated = repeated || ((int64_t)nwork * 2 >= ncols &&
                                 (double)m->nnz * 32.0 >= (double)ncols * (double)ncols);
