@@ -139,3 +139,65 @@ def test_time_budget_cuts_columns_off_and_reports_what_they_reached(ml100k):
     assert 0 < st2["D"].sum() < st["D"].sum()
     _, st3, _, _ = O.learn_cd(R, order=O.ORDER_LOCAL, aty=O.ATY_GRAM, nthreads=2, return_stats=True, chunk=1)
     assert (st3["conv"] >= 0).all() and abs(st3["D"].sum() - st["D"].sum()) <= 0.01 * st["D"].sum()
+
+
+def test_item_space_restatement_walks_to_the_same_model():
+    """The algebra the item-space kernel (cd_gram.hpp) rests on, checked on the CPU in fp64 and
+    independently of any GPU code: carrying g_i = a_i.r = aTy_i - sum_j G_ij x_j over the ITEMS
+    (G = R^T R, an update is g -= d G[i, :]) and visiting num = g_i + x_i G_ii is the
+    coordinate descent of cd.c:112-139 -- a plain numpy walk of that form, in the tile's visiting
+    order (union of the 32 active sets, keyed permutation, per-problem cap and stop rule,
+    epsilon rule of cd.c:27), reaches the oracle's tile walk (user space, three passes per visit)
+    to the last float of the model, with the same sweep counts."""
+    rng = np.random.default_rng(3)
+    R = sp.random(400, 90, density=0.12, format="csr", random_state=rng, dtype=np.float32)
+    R.data = rng.integers(1, 6, R.nnz).astype(np.float32)
+    R.sort_indices()
+    l1, l2, tol, seed, eps = 0.5, 1.5, 1e-9, 5, 1e-7
+    order = O.tile_work_order(R)
+    Wo, so, _, _ = O.learn_cd_tile(R, tileP=32, order=order, l1r=l1, l2r=l2, optTol=tol, seed=seed,
+                                   return_stats=True)
+    L = O.lib()
+    A = R.toarray().astype(np.float64)
+    G = A.T @ A
+    ncols = R.shape[1]
+    nnz_col = np.diff(R.tocsc().indptr)
+    cn = np.sqrt(np.diag(G).astype(np.float32)).astype(np.float32).astype(np.float64)   # setup.c:130
+    W = np.zeros((ncols, ncols), np.float32)
+    sweeps = np.zeros(ncols, np.int32)
+    for g in range((order.size + 31) // 32):
+        members = order[g * 32:(g + 1) * 32]
+        aty = {int(iC): G[:, iC].astype(np.float32).astype(np.float64) for iC in members}   # float key
+        act = {iC: (aty[iC] > l1) & (np.arange(ncols) != iC) for iC in aty}
+        union = np.flatnonzero(np.any([act[iC] for iC in aty], axis=0))
+        nu = union.size
+        for iC in aty:
+            x = np.zeros(ncols)
+            gvec = aty[iC].copy()            # g = aTy - G xeff, xeff = 0
+            maxit = min(50 * int(nnz_col[iC]), 10000)
+            t = 0
+            while t < maxit:
+                key = L.oracle_perm_key(seed, g, t)
+                dlt = 0.0
+                for p in range(nu):
+                    i = int(union[L.oracle_perm_index(p, nu, key)])
+                    if not act[iC][i]:
+                        continue
+                    xi = x[i]
+                    xeff = xi if abs(xi) > eps else 0.0
+                    num = gvec[i] + xeff * G[i, i]
+                    nx = (num - l1) / (cn[i] * cn[i] + l2) if num > l1 else 0.0
+                    neff = nx if abs(nx) > eps else 0.0
+                    if neff != xeff:
+                        gvec -= (neff - xeff) * G[i, :]
+                    x[i] = nx
+                    dlt += (nx - xi) ** 2
+                t += 1
+                if dlt < tol:
+                    break
+            sweeps[iC] = t if (t < maxit or dlt < tol) else maxit + 1
+            keep = np.abs(x) > eps
+            W[keep, iC] = x[keep].astype(np.float32)
+    d = abs(sp.csc_matrix(W) - Wo)
+    assert Wo.nnz > 500 and (d.max() if d.nnz else 0.0) <= 2e-7
+    assert (sweeps == so["sweeps"]).mean() >= 0.98
