@@ -45,3 +45,31 @@ def test_kernel_hash_ignores_comments_and_layout(tmp_path, monkeypatch):
     assert len(h) == 16 and h == bench.kernel_hash()
     entries = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]
     assert any(e.get("kernel_hash") == h for e in entries)
+
+
+def test_dry_run_projection_adds_up():
+    """bench.py --dry-run-world N on a stand-in matrix: every shard of the step
+    is solved once after one warm-up, the spread is (max - min) / mean of the kernel times, and the
+    projected command = start-up + broadcast + warm-up + 20 steps at the slowest shard's wall
+    time + the whole-matrix step, held against the driver's 1800 s."""
+    calls = []
+
+    class Mat(object):
+        nrows = 1000000
+
+        def learn(self, col_begin, col_end, shard, **kw):
+            calls.append((col_begin, col_end, shard))
+            r = shard[0]
+            return None, {"ncols_solved": (col_end - col_begin) // shard[1], "kernel_ms": 50000.0 + 500.0 * r,
+                          "alg_bytes": 3.6e14}
+
+    args = _default_args(dry_run_world=8)
+    out = bench.dry_run(args, Mat(), 100000, 8192, {}, 10 ** 9)
+    assert calls[0] == (0, 2048, (0, 8))                       # the warm-up: 1/32 of the range
+    assert [c[2] for c in calls[1:]] == [(r, 8) for r in range(8)] and calls[1][:2] == (0, 65536)
+    assert out["dry_run_world"] == 8 and [x["rank"] for x in out["ranks"]] == list(range(8))
+    assert abs(out["kernel_ms_spread"] - 3500.0 / 51750.0) < 1e-3
+    p = out["projected_command_s"]
+    assert abs(p["total"] - (p["start_up_and_generate"] + p["broadcast_R"] + p["warmup"] + p["timed_steps"]
+                             + p["whole_matrix_step"])) < 0.2
+    assert p["limit"] == 1800.0 and isinstance(p["fits"], bool)
