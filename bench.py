@@ -154,7 +154,15 @@ def main():
     # asks for item-space CD explicitly; it is reported under its own key otherwise.
     if args.kernel != 5:
         os.environ["SLIM_GPU_NO_GRAM"] = "1"
-        os.environ["SLIM_GPU_NO_GRAMCD"] = "1"
+    # `value` and `roofline` price the RESIDUAL kernel (SURVEY.md 8(d)'s formula is its traffic):
+    # it is pinned explicitly for the timed steps of the synthetic workloads, because the
+    # engine's own choice (SLIMGPU_KERNEL_AUTO, what SLIM_Learn takes by default) is item space
+    # there since round 5 -- that path is reported beside it as item_space_step / item_space_grid
+    # with its own byte model.  --kernel 5 times item space itself; --kernel 0 on ml100k is the
+    # one-wavefront-per-item kernel.
+    timed_kernel = args.kernel
+    if timed_kernel == 0 and args.workload != "ml100k":
+        timed_kernel = 3
 
     # ---- the workload, resident in HBM before anything is timed ---------------------
     t_gen = time.time()
@@ -208,7 +216,7 @@ def main():
     else:
         span = min(ncols, per_gpu * world)
     warm_span = min(span, world * (args.warmup_batch or max(256, per_gpu // 32)))
-    opts = dict(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=args.seed, kernel=args.kernel)
+    opts = dict(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=args.seed, kernel=timed_kernel)
     if args.cluster:
         opts["cluster"] = args.cluster
 
@@ -357,7 +365,7 @@ def main():
                                "round-robin) over %d GPU(s), R replicated" % world,
                 "kernel": kname,
                 "carried_between_steps": "nothing (screen-sum cache and the automatic switch to "
-                                         "item-space CD are off for the timed steps)"
+                                         "item-space CD are off for the timed steps: kernel pinned)"
                                          if args.kernel != 5 else "G = R^T R, built by the first step",
                 "generate_s": round(t_gen, 2), "stage_s": round(t_stage, 2),
             },
@@ -382,9 +390,11 @@ def main():
             out["strong_whole_matrix"] = strong_whole
         if world == 1:
             out["parity"] = ml100k_parity(dev.index)
+        # the engine's default path on this workload, under its own keys (~60 s together; they run
+        # BEFORE the CPU leg, which fits itself into whatever is left of the wall budget)
         if world == 1 and args.workload == "c4" and args.scale == 1 and args.kernel != 5 \
-                and not args.no_item_space and WALL_BUDGET_S - (time.time() - T_START) > 620:
-            out["item_space_step"] = item_space_step(mat, last_b, span, opts, W)
+                and not args.no_item_space and WALL_BUDGET_S - (time.time() - T_START) > 200:
+            out["item_space_step"] = item_space_step(args, mat, last_b, span, opts, W)
             out["item_space_grid"] = item_space_grid(args, dev)
         if world == 1 and args.cpu_seconds > 0 and args.workload != "ml100k":
             out["cpu_baseline"] = cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols,
@@ -435,23 +445,38 @@ def dry_run(args, mat, ncols, per_gpu, opts, nnz):
                     "is measured is the evenness of the shards and the step time they imply"}
 
 
-def item_space_step(mat, b, span, opts, W_res):
+def item_space_step(args, mat, b, span, opts, W_res):
     """Secondary figure, under its own key: the LAST timed step once more -- the same columns of
-    the same matrix, from scratch -- in item space (cd_gram.hpp): G = R^T R of the whole matrix is
-    built inside the measured time and nothing is carried in.  Also a parity figure: the two
-    kernels walk the same visiting order, so their models differ by fp32 rounding only."""
+    the same matrix, from scratch -- on the path SLIM_Learn takes by default (SLIMGPU_KERNEL_AUTO:
+    item space, cd_gram*.hpp): G = R^T R of the whole matrix is built inside the measured time and
+    nothing is carried in.  Also a parity figure: the two kernels walk the same visiting order, so
+    their models differ by fp32 rounding only.  Its roofline object uses that kernel's own byte
+    model (bytes of G streamed, SLIMGPU_LastStats.gram_bytes) over its HIP-event time."""
     import scipy.sparse as sp
     saved = {k: os.environ.pop(k, None) for k in ("SLIM_GPU_NO_GRAM", "SLIM_GPU_NO_GRAMCD")}
     try:
         t0 = time.perf_counter()
-        Wi, st = mat.learn(col_begin=b, col_end=b + span, **dict(opts, kernel=5))
+        Wi, st = mat.learn(col_begin=b, col_end=b + span, **dict(opts, kernel=0))
         dt = time.perf_counter() - t0
         d = abs(sp.csc_matrix(Wi) - sp.csc_matrix(W_res))
+        ks = st["kernel_ms"] * 1e-3
+        gbps = st["gram_bytes"] / max(ks, 1e-9) / 1e9
+        traffic = pmc_traffic(args, span, "item_space_step", True)
         return {"columns": int(span), "seconds": round(dt, 2), "value": span / dt, "unit": "item-columns/s",
-                "G_build_s": round(st["gram_build_ms"] * 1e-3, 2), "kernel_s": round(st["kernel_ms"] * 1e-3, 2),
+                "G_build_s": round(st["gram_build_ms"] * 1e-3, 2), "kernel_s": round(ks, 2),
                 "rows_of_G_read": int(st["gram_rows"]), "kernel": KERNEL_NAMES.get(st["kernel"], st["kernel"]),
+                "chosen_by": "SLIMGPU_KERNEL_AUTO (the engine's default)",
                 "max_abs_dW_vs_the_timed_step": float(d.max()) if d.nnz else 0.0,
                 "nnzW": int(st["nnzW"]),
+                "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": gbps / HBM_PEAK_GBS,
+                             "traffic": float(traffic) if traffic else None,
+                             "achieved_physical": float(traffic) / ks / 1e9 if traffic and ks > 0 else None,
+                             "kernel_ms_per_launch": st["kernel_ms"], "alg_bytes_per_launch": st["gram_bytes"],
+                             "note": "byte model of the item-space kernel: the bytes of G its updates and "
+                                     "warm-start folds stream (SLIMGPU_LastStats.gram_bytes) over the solver's "
+                                     "HIP-event time (union lists included); traffic: PMC bytes of the same "
+                                     "launch (profiles/pmc_traffic.json, matched by configuration and source hash)"},
                 "note": "the columns of the last timed step, from scratch, G = R^T R (all 100 000 items) built "
                         "inside `seconds`; not `value`: SURVEY.md 8(d) prices the residual kernel's traffic"}
     except Exception as e:   # noqa: BLE001 -- an extra must not cost the line
@@ -580,16 +605,22 @@ def ml100k_parity(device):
 
 
 KERNEL_SOURCES = ("cd_tile.hpp", "cd_wave.hpp", "cd_perm.hpp", "engine.hip", "tile_inst.hpp")
+# the item-space path on top of those (its launches, G builder and kernels)
+GRAM_SOURCES = ("cd_gram.hpp", "cd_gramr.hpp", "gram_pack.hpp", "gram_inst.hpp")
 
 
-def kernel_hash():
+def kernel_hash(kind="tile"):
     """Fingerprint of the solver sources: a PMC figure collected for another build of the
-    kernels must not be reported for this one."""
+    kernels must not be reported for this one.  kind "gram": the item-space path's sources too."""
     import hashlib
     import re
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "slim_amd", "csrc", name)) as f:
+    names = KERNEL_SOURCES + (GRAM_SOURCES if kind == "gram" else ())
+    for name in names:
+        path = os.path.join(ROOT, "slim_amd", "csrc", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
             text = f.read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # comments and layout do not
         text = re.sub(r"//[^\n]*", "", text)                       # change the machine code
@@ -615,7 +646,7 @@ def pmc_traffic(args, columns, kernel, binary, world=1):
         if (m["workload"] == args.workload and float(m["scale"]) == float(args.scale) and
                 m["columns_per_step_per_gpu"] == columns and m["kernel"] == kernel and
                 bool(m["binary"]) == bool(binary) and int(m.get("seed", 1)) == int(args.seed) and
-                e.get("kernel_hash") == kernel_hash()):
+                e.get("kernel_hash") == kernel_hash("gram" if kernel.startswith("item_space") else "tile")):
             return e["traffic_bytes_per_launch"]
     return None
 

@@ -1,0 +1,524 @@
+// cd_gramr.hpp -- item-space coordinate descent with g ON CHIP and G streamed as byte planes.
+//
+// cd_gram.hpp carries g_i = a_i . r over the items and pays one row of G per update.  Measured on
+// the 1M x 100K matrix (profiles/r05/support_overlap_c4.txt): a problem makes ~14 300 updates
+// (2 600 coefficients x 5.5 sweeps), the supports of the 32 problems of a tile are as good as
+// independent (32 supports of 2.6 % cover 45 % of the items: sharing factor 1.8), and every item is
+// in every active set -- so neither sharing rows among problems nor skipping coordinates removes
+// work, and the lever that is left is BYTES PER ENTRY OF G and what else an update moves:
+//
+//   * the row comes as byte planes in popularity order (gram_pack.hpp): ~1.15 bytes per entry
+//     instead of 4, decoded exactly, so the fmaf sequence is the float kernel's;
+//   * g never leaves the compute unit.  100 000 floats do not fit the LDS (160 KB), but LDS +
+//     registers hold them: a workgroup of 512 threads (two wavefronts per SIMD: 256 VGPRs each)
+//     owns g in 16-entry chunks, thread t the ranks [16 (t + 512 k), +16) for k = 0 .. K-1 -- the
+//     first KR groups in REGISTERS (16 KR VGPRs per lane), the last KL groups in LDS.  An update is
+//     then one 16-byte load per thread and group plus FMAs on values the thread already holds: no
+//     pass over g in HBM (cd_gram_kernel<8,0>: 0.8 MB per 512-visit batch) and no batch of deferred
+//     updates kept current through 512 single-element gathers per update;
+//   * a visit needs g_i of ITS coordinate, which sits in some thread's register: before a batch of
+//     64 visits every wavefront exports the entries it owns (a wave-uniform register select -- the
+//     visit's coordinate is known to all) to a 64-float LDS line, entries of the LDS groups are read
+//     in place.  Then the batch runs like cd_gram.hpp's LDS form: every wavefront evaluates the 64
+//     visits redundantly, the first lane whose coefficient moves is the next change of the
+//     sequential algorithm, its row is streamed and applied by all threads to what they own, and
+//     every lane corrects the g of its own visit with ONE entry of that row.
+//
+// Same update rule (cd.c:121-128), same epsilon rule (cd.c:27), same cap (estimate.c:448-449), same
+// stop rule (cd.c:135), same visiting order (cd_perm.hpp over the tile's union list) and -- the
+// planes decode exactly -- the same float arithmetic as cd_gram.hpp; checked against the oracle's
+// tile walk and against that kernel.
+//
+// Byte model: per update hi_k(row) and hi2_k(row) groups of 8192 bytes on top of the row's ncols
+// bytes of `lo` (counted per problem on the device: SolveArgs.st_B), nothing else of size.
+#pragma once
+#include <utility>
+
+#include "cd_tile.hpp"
+#include "gram_pack.hpp"
+
+namespace slimamd {
+
+// one group of this thread's g: 16 consecutive registers, so that entry e of a group can be read
+// with a wave-uniform e by ONE v_movrels (register-indirect move) -- a switch over 160 constant
+// indices made the register allocator spill a hundred live ranges around it
+typedef float gramr_v16 __attribute__((ext_vector_type(16)));
+
+// The groups are members of a struct reached by compile-time indices only (an array indexed by
+// the variable of an unrolled loop stays in scratch memory: the promotion to registers runs
+// before the loops are unrolled).
+template <int N>
+struct GramrRegs {
+  gramr_v16 v;
+  GramrRegs<N - 1> rest;
+};
+template <>
+struct GramrRegs<0> {};
+template <int I, int N>
+__device__ __forceinline__ gramr_v16& gramr_reg(GramrRegs<N>& r) {
+  if constexpr (I == 0) return r.v;
+  else return gramr_reg<I - 1>(r.rest);
+}
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// entry e of group k for wave-uniform k, e
+template <int KRA>
+__device__ __forceinline__ float gramr_sel(GramrRegs<KRA>& gr, const int k, const int e) {
+  float v = 0.0f;
+  static_for<KRA>([&](auto kc) __attribute__((always_inline)) {
+    constexpr int n = decltype(kc)::value;
+    if (k == n) {
+      // (the copy goes through an empty asm: otherwise the optimizer folds "load the group, take
+      // element e" into one scalar load at a variable address and the whole struct stays in memory)
+      gramr_v16 t = gramr_reg<n>(gr);
+      asm volatile("" : "+v"(t));
+      v = t[e];
+    }
+  });
+  return v;
+}
+
+// KR groups of 8192 ranks in registers, KL groups in LDS (dynamic: KL * 32 KB).
+template <int KR, int KL>
+__global__ __launch_bounds__(kGramrNT, (KR <= 2 && KL == 0) ? 4 : 2) void cd_gramr_kernel(
+    const DevMatrix A, const SolveArgs S, const GramPacked P) {
+  constexpr int NT = kGramrNT, K = KR + KL;
+  constexpr int KRA = KR > 0 ? KR : 1;
+  constexpr int R0 = KR * kPackGroup;  // first rank held in LDS
+  static_assert(KR <= 12, "register select covers 12 groups");
+  extern __shared__ __attribute__((aligned(16))) float g_lds[];  // [KL][4][NT] float4: conflict-free
+  __shared__ float s_gB[64];
+  __shared__ int s_p, s_na;
+  __shared__ unsigned long long s_D, s_U;
+  __shared__ unsigned long long s_off;
+  __shared__ int s_nz;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = uni(tid >> 6);
+  const int ncols = A.ncols;
+  const int n4 = S.ncols_pad >> 2;
+  const int nchunks = P.nchunks;
+  const float l1 = S.l1, l2 = S.l2;
+  const float* __restrict__ Gm = S.G;  // floats: aTy of a problem (x init, active set)
+  const int64_t ld = S.G_ld;
+  float* const x = S.xslab + (int64_t)blockIdx.x * S.x_stride;  // [ncols_pad], item ids, -inf = inactive
+  float4* const x4 = reinterpret_cast<float4*>(x);
+  float4* const gl4 = reinterpret_cast<float4*>(g_lds);
+  const int64_t* __restrict__ colptr = A.colptr;
+  const int32_t* __restrict__ rank_of = P.rank_of;
+
+  GramrRegs<KRA> gr;
+
+  // g += nd * G[row, :] on what this thread owns.  (plo, phi, ph2, hk, h2k): the row's planes.
+  // Every load is `global_load_dwordx4 v, v_off, s[base]` with ONE 32-bit offset register per
+  // group, clamped to the row's last chunk (threads behind the end of the row read that chunk again
+  // and update entries of g no visit ever reads) -- no exec masking, no 64-bit address per group.
+  const uint32_t voff0 = 16u * (uint32_t)tid;
+  const uint32_t vlast = 16u * (uint32_t)(nchunks - 1);
+  auto apply = [&](const uint8_t* __restrict__ plo, const uint8_t* __restrict__ phi,
+                   const uint8_t* __restrict__ ph2, const int hk, const int h2k,
+                   const float nd) __attribute__((always_inline)) {
+    constexpr int GRP = 4;
+    static_for<(K + GRP - 1) / GRP>([&](auto k0c) __attribute__((always_inline)) {
+      constexpr int k0 = decltype(k0c)::value * GRP;
+      uint4 l[GRP], h[GRP];
+      static_for<GRP>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, k = k0 + u;
+        if constexpr (k < K) {
+          const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
+          l[u] = ld_off<uint4>(plo, vo);
+          if (k < hk) h[u] = ld_off<uint4>(phi, vo);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);  // (the loads of ONE group of GRP chunks in flight, not of all)
+      static_for<GRP>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, k = k0 + u;
+        if constexpr (k < K) {
+          float f[16];
+          unpack16(l[u], f);
+          if (k < hk) {
+            unpack16_add(h[u], 256.0f, f);
+            if (k < h2k) {
+              const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
+              unpack16_add(ld_off<uint4>(ph2, vo), 65536.0f, f);
+            }
+          }
+          if constexpr (k < KR) {
+            gramr_v16& g = gramr_reg<k>(gr);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) g[e] = fmaf(nd, f[e], g[e]);
+            // (pins the group's FMAs HERE: left alone, the optimizer sinks the FMAs of all groups
+            // behind the last `k < hk` join and keeps 16 decoded floats per group alive until then)
+            asm volatile("" : "+v"(g));
+          } else {
+            float4* const gp = gl4 + (k - KR) * 4 * NT + tid;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float4 v = gp[j * NT];
+              v.x = fmaf(nd, f[4 * j + 0], v.x);
+              v.y = fmaf(nd, f[4 * j + 1], v.y);
+              v.z = fmaf(nd, f[4 * j + 2], v.z);
+              v.w = fmaf(nd, f[4 * j + 3], v.w);
+              gp[j * NT] = v;
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  };
+  int nrows_read = 0, ngroups_read = 0;  // rows applied (fold + updates), hi / hi2 groups among them
+  // float index in g_lds of rank r >= R0
+  auto lds_index = [&](const int r) __attribute__((always_inline)) -> int {
+    const int rr = r - R0;
+    const int kk = rr >> 13, t = (rr >> 4) & (NT - 1), e = rr & 15;
+    return ((kk * 4 + (e >> 2)) * NT + t) * 4 + (e & 3);
+  };
+
+  // g of the lanes' coordinates (rank r, wanted where `want`): every wavefront exports the entries
+  // its threads hold in registers (a wave-uniform register select per entry) to one 64-float LDS
+  // line, entries of the LDS groups are copied there too -- nobody may read g_lds once the first
+  // wavefront has started applying a batch's rows.  Called by all threads; two barriers.
+  auto fetch_g = [&](const bool want, const int r) __attribute__((always_inline)) -> float {
+    __syncthreads();  // earlier row updates are in LDS; s_gB is free
+    const bool in_lds = r >= R0;
+    if (KR > 0) {
+      uint64_t mine = __ballot(want && !in_lds && (((r >> 4) & (NT - 1)) >> 6) == wave);
+      while (mine) {
+        const int b = __builtin_ctzll(mine);
+        mine &= mine - 1ull;
+        const int rb = lane_bcast(r, b);
+        const float v = gramr_sel<KRA>(gr, rb >> 13, rb & 15);
+        if (lane == ((rb >> 4) & 63)) s_gB[b] = v;
+      }
+    }
+    if (KL > 0 && wave == 0 && want && in_lds) s_gB[lane] = g_lds[lds_index(r)];
+    __syncthreads();
+    return s_gB[lane];
+  };
+
+  for (;;) {
+    if (tid == 0) {
+      s_p = atomicAdd(S.queue, 1);
+      s_na = 0;
+      s_D = 0;
+      s_U = 0;
+    }
+    __syncthreads();
+    const int p = s_p;
+    if (p >= S.nwork) break;
+    const int item = uni(S.order[p]);
+    const int grp = p >> 5;
+    const uint32_t gkey = (uint32_t)(grp * S.shard_count + S.shard_index);
+    const int* __restrict__ ul = S.ulist + (int64_t)grp * S.u_stride;
+    const int nunion = uni(S.tile_nunion[grp]);
+    const float* __restrict__ arow = Gm + (int64_t)item * ld;  // aTy of this problem (floats, item ids)
+
+    // -- x = 0 on the active set {i != iC : aTy_i > l1} (estimate.c:433-444), -inf elsewhere
+    {
+      const float4* __restrict__ a4 = reinterpret_cast<const float4*>(arow);
+      int na = 0;
+      for (int c = tid; c < n4; c += NT) {
+        const float4 a = a4[c];
+        const int i0 = c << 2;
+        float4 xs;
+        const bool a0 = i0 + 0 < ncols && i0 + 0 != item && a.x > l1;
+        const bool a1 = i0 + 1 < ncols && i0 + 1 != item && a.y > l1;
+        const bool a2 = i0 + 2 < ncols && i0 + 2 != item && a.z > l1;
+        const bool a3 = i0 + 3 < ncols && i0 + 3 != item && a.w > l1;
+        xs.x = a0 ? 0.0f : kInactive;
+        xs.y = a1 ? 0.0f : kInactive;
+        xs.z = a2 ? 0.0f : kInactive;
+        xs.w = a3 ? 0.0f : kInactive;
+        na += (int)a0 + (int)a1 + (int)a2 + (int)a3;
+        x4[c] = xs;
+      }
+      na = (int)wave_sum((float)na);  // (< 2^24: exact)
+      if (lane == 0 && na) atomicAdd(&s_na, na);
+    }
+    // -- warm start (estimate.c:453-464): previous coefficients of the coordinates active now (a
+    //    negative value ends up 0 there: the flag-clearing loop resets every x < 0)
+    int64_t fe = 0, we = 0;  // entries of the previous column still to fold
+    if (S.icolptr != nullptr && item < S.incols) {
+      __syncthreads();
+      fe = uni(S.icolptr[item]);
+      we = uni(S.icolptr[item + 1]);
+      for (int64_t e = fe + tid; e < we; e += NT) {
+        const int k = S.icolind[e];
+        if (k < ncols && tile_active(x[k])) {
+          const float v = S.icolval[e];
+          x[k] = v < 0.0f ? 0.0f : v;
+        }
+      }
+    }
+    static_for<KRA>([&](auto kc) __attribute__((always_inline)) {
+      gramr_reg<decltype(kc)::value>(gr) = (gramr_v16)(0.0f);
+    });
+#pragma unroll
+    for (int k = 0; k < KL; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gl4[(k * 4 + j) * NT + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    int maxit = 0;
+    {
+      const int64_t cap = 50 * (uni(colptr[item + 1]) - uni(colptr[item]));  // estimate.c:448-449
+      maxit = cap < (int64_t)S.maxniters ? (int)cap : S.maxniters;
+    }
+    int niters = 0, conv = 0;
+    uint32_t Dq = 0, Uq = 0;  // SURVEY.md 8(d) counters, per lane and sweep (same in every wave)
+    nrows_read = 0;
+    ngroups_read = 0;
+
+    // ONE loop carries the whole problem, so that the registers holding g see one site that
+    // updates them (apply) and one that reads them out (fetch_g) -- with a site per phase the
+    // register allocator splits the 160 live ranges around each and spills hundreds of them.
+    //   phase 0  set-up: g = aTy (0 + 1 * G[iC, :] from the planes: the same floats) and the
+    //            warm-start fold g -= x_j G[j, :] (cd.c:108-110 in item space)
+    //   phase 1  sweeps (cd.c:112-139): a pass = one batch of 64 visits
+    //   phase 2  output (estimate.c:477-505): a pass = 64 item ids, ascending
+    int phase = 0;
+    bool init_row = true;
+    int t = 0, p0 = 0;      // sweep, first position of the batch
+    float dlt = 0.0f;
+    PermCtx pc = perm_make(1u, 0u);
+    int i_n = 0, r_n = 0, len_n = 0;  // header of the NEXT batch (loaded one batch ahead: its three
+    float xi_n = kInactive, sq_n = 0.0f, cn_n = 0.0f;  // dependent loads overlap this batch's updates)
+    auto header = [&](const int q0) __attribute__((always_inline)) {
+      const int pos = q0 + lane;
+      i_n = 0;
+      xi_n = kInactive;
+      if (pos < nunion) {
+        i_n = ul[perm_index(pc, (uint32_t)pos)];
+        xi_n = x[i_n];
+      }
+      r_n = rank_of[i_n];
+      sq_n = 0.0f;
+      cn_n = 0.0f;
+      len_n = 0;
+      if (tile_active(xi_n)) {
+        sq_n = A.csq[i_n];
+        cn_n = A.cnorm[i_n];
+        len_n = (int)(colptr[i_n + 1] - colptr[i_n]);
+      }
+    };
+    int ib = 0, wpos = 0, nz = 0;  // output pass
+    unsigned long long off = 0;
+    bool fits = false;
+    double e2 = 0.0, reg = 0.0;
+
+    for (;;) {  // passes
+      // -- what the lanes of this pass are about
+      bool want = false;
+      int r = 0, i = 0, len = 0;
+      float xi = kInactive, sq = 0.0f, cn = 0.0f;
+      bool part = false, keep = false;
+      uint64_t mkeep = 0;
+      if (phase == 1) {
+        i = i_n;
+        r = r_n;
+        len = len_n;
+        xi = xi_n;
+        sq = sq_n;
+        cn = cn_n;
+        part = tile_active(xi);
+        if (p0 + 64 < nunion) header(p0 + 64);
+        want = part;
+      } else if (phase == 2) {
+        i = ib + lane;
+        xi = i < ncols ? x[i] : kInactive;
+        const bool act = tile_active(xi);
+        keep = act && fabsf(xi) > kEps;
+        if (act) reg += 0.5 * (double)l2 * (double)xi * (double)xi + (double)l1 * (double)fabsf(xi);
+        mkeep = __ballot(keep);
+        if (mkeep == 0) {  // nothing kept among these 64 ids
+          ib += 64;
+          if (ib >= ncols) break;
+          continue;
+        }
+        r = keep ? rank_of[i] : 0;
+        want = keep;
+      }
+      const float g0 = fetch_g(want, r);  // (the one site that reads g out)
+      float gi = g0;
+      uint64_t pend = 0;
+      if (phase == 1) {
+        pend = __ballot(part);
+        Dq += (uint32_t)len;
+      }
+      // -- the rows this pass applies
+      for (;;) {
+        int row = 0;
+        float nd = 0.0f;
+        if (phase == 0) {
+          bool have = false;
+          if (init_row) {
+            row = item;
+            nd = 1.0f;
+            have = true;
+          } else {
+            while (fe < we) {
+              const int kk = uni(S.icolind[fe]);
+              ++fe;
+              if (kk < ncols) {
+                const float xk = uni(x[kk]);
+                if (xk > kEps) {
+                  row = kk;
+                  nd = -xk;
+                  have = true;
+                  break;
+                }
+              }
+            }
+          }
+          if (!have) break;
+        } else if (phase == 1) {
+          if (pend == 0) break;
+          const float xeff = (xi > kEps || xi < -kEps) ? xi : 0.0f;
+          const float num = gi + xeff * sq;
+          const float nx = num > l1 ? (num - l1) / (cn * cn + l2) : 0.0f;
+          const float neff = (nx > kEps || nx < -kEps) ? nx : 0.0f;
+          const float d = neff - xeff;
+          const uint64_t m = __ballot(part && nx != xi) & pend;
+          if (m == 0) break;  // nothing else in the batch moves
+          const int f = __builtin_ctzll(m);
+          const float d_f = lane_bcast(d, f);
+          const float nx_f = lane_bcast(nx, f), xi_f = lane_bcast(xi, f);
+          dlt += (nx_f - xi_f) * (nx_f - xi_f);
+          if (wave == 0 && lane == f) x[i] = nx;
+          pend = f == 63 ? 0ull : (pend & ~((2ull << f) - 1ull));
+          if (d_f == 0.0f) continue;  // (a change below the epsilon of cd.c:27 moves no g)
+          if (lane == f) Uq += (uint32_t)len;
+          row = lane_bcast(i, f);
+          nd = -d_f;
+        } else {
+          break;
+        }
+        const int hk = uni(P.hi_k[row]), h2k = uni(P.hi2_k[row]);
+        const uint8_t* __restrict__ plo = P.lo + (int64_t)row * P.ldb;
+        const uint8_t* __restrict__ phi = P.hi + uni(P.hi_off[row]);
+        const uint8_t* __restrict__ ph2 = P.hi2 + uni(P.hi2_off[row]);
+        // a visit's lane: the entry of the row its own coordinate needs (three byte loads issued
+        // together, ahead of the row; behind a plane's prefix the lane reads byte 0 and drops it)
+        const bool in1 = r < hk * kPackGroup, in2 = r < h2k * kPackGroup;
+        const uint32_t b0 = plo[r], b1 = phi[in1 ? r : 0], b2 = ph2[in2 ? r : 0];
+        apply(plo, phi, ph2, hk, h2k, nd);  // (the one site that updates g)
+        float gsel = (float)b0;
+        gsel = in1 ? fmaf(256.0f, (float)b1, gsel) : gsel;
+        gsel = in2 ? fmaf(65536.0f, (float)b2, gsel) : gsel;
+        if (init_row) {  // (the byte model counts updates and folds; this row was the set-up)
+          init_row = false;
+        } else {
+          ++nrows_read;
+          ngroups_read += hk + h2k;
+        }
+        gi = fmaf(nd, gsel, gi);
+      }
+      // -- what comes next
+      if (phase == 1) {
+        p0 += 64;
+        if (p0 < nunion) continue;
+        if (wave == 0) {  // (a lane's share of one sweep fits 32 bits; the totals do not)
+          if (Dq) atomicAdd(&s_D, (unsigned long long)Dq);
+          if (Uq) atomicAdd(&s_U, (unsigned long long)Uq);
+        }
+        Dq = 0;
+        Uq = 0;
+        if (dlt < S.opt_tol) {  // cd.c:135-138
+          conv = 1;
+          niters = t + 1;
+        } else {
+          ++t;
+        }
+      } else if (phase == 2) {
+        if (keep) {
+          e2 += (double)xi * ((double)arow[i] + (double)g0);
+          if (fits && wave == 0) {
+            const int64_t dst = (int64_t)off + wpos + __popcll(mkeep & ((1ull << lane) - 1ull));
+            S.out_ind[dst] = i;
+            S.out_val[dst] = xi;
+          }
+        }
+        wpos += __popcll(mkeep);
+        ib += 64;
+        if (ib >= ncols) break;
+        continue;
+      }
+      // here: the set-up is done, or a sweep has ended -- start the next sweep or the output
+      bool sweep = false;
+      if (!conv) {
+        if (t >= maxit) {  // loop exhausted without convergence: niters = t + 1 (cd.c:140)
+          niters = maxit + 1;
+        } else if (nunion == 0) {  // (an empty active set: one sweep that changes nothing)
+          conv = 1;
+          niters = t + 1;
+        } else {
+          sweep = true;
+        }
+      }
+      if (sweep) {
+        phase = 1;
+        p0 = 0;
+        dlt = 0.0f;
+        pc = perm_make((uint32_t)nunion, perm_key(S.seed, gkey, (uint32_t)t));
+        header(0);
+        continue;
+      }
+      // wavefront 0 counts the kept coefficients and claims the arena space
+      if (wave == 0) {
+        int cnt = 0;
+        for (int jb = 0; jb < ncols; jb += 64) {
+          const int j = jb + lane;
+          const float xv = j < ncols ? x[j] : kInactive;
+          cnt += __popcll(__ballot(tile_active(xv) && fabsf(xv) > kEps));
+        }
+        if (lane == 0) {
+          s_off = atomicAdd(S.out_cursor, (unsigned long long)cnt);
+          s_nz = cnt;
+        }
+      }
+      __syncthreads();
+      off = s_off;
+      nz = s_nz;
+      fits = (int64_t)(off + (unsigned long long)nz) <= S.out_cap;
+      phase = 2;
+      ib = 0;
+      wpos = 0;
+      if (ncols <= 0) break;
+    }
+    // ||y - A x||^2 = |a_iC|^2 - sum_i x_i (aTy_i + g_i) over the kept coefficients (every
+    // wavefront formed the same sums; wavefront 0 reports)
+    if (wave == 0) {
+      for (int o = 32; o > 0; o >>= 1) {
+        e2 += __shfl_xor(e2, o);
+        reg += __shfl_xor(reg, o);
+      }
+      if (lane == 0) {
+        const float err = (float)(0.5 * ((double)A.csq[item] - e2));
+        if (!fits) atomicMax(S.overflow, 1);
+        S.out_cnt[item] = fits ? nz : -nz - 1;
+        S.out_off[item] = (int64_t)off;
+        S.st_na[item] = s_na;
+        S.st_sweeps[item] = niters;
+        S.st_conv[item] = conv;
+        S.st_D[item] = (int64_t)s_D;
+        S.st_U[item] = (int64_t)s_U;
+        S.st_G[item] = nrows_read;  // (the engine reports the staging pass's G for the column)
+        S.st_B[item] = (int64_t)nrows_read * P.ldb + (int64_t)ngroups_read * kPackGroup;
+        S.st_err[item] = err;
+        S.st_obj[item] = err + (float)reg;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace slimamd

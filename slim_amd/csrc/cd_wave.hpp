@@ -131,6 +131,7 @@ struct SolveArgs {
   int64_t* st_G;
   int64_t* st_D;
   int64_t* st_U;
+  int64_t* st_B;  // item-space kernels: bytes of G streamed by the column's updates and folds
   float* st_err;
   float* st_obj;
 };

@@ -25,6 +25,7 @@
 
 #include "tile_inst.hpp"
 #include "gram_inst.hpp"
+#include "gramr_inst.hpp"
 #include "cd_wave.hpp"
 #include "engine.hpp"
 #include "host_csr.hpp"
@@ -76,6 +77,13 @@ struct slimgpu_matrix {
   int64_t G_ld = 0;
   bool G_ready = false;
   double G_build_ms = 0;
+  // G as byte planes in popularity order (gram_pack.hpp), what cd_gramr.hpp streams: built from
+  // the float G right after it, when every entry is a non-negative integer below 2^24
+  Buf ws_Glo, ws_Ghi, ws_Ghi2, ws_hioff, ws_hi2off, ws_hik, ws_hi2k, ws_rankof, ws_itemof;
+  int64_t Gp_ldb = 0;
+  int32_t Gp_nchunks = 0;
+  bool Gp_ready = false, Gp_tried = false;
+  double Gp_bytes_per_row = 0;      // average bytes of a packed row (lo + hi + hi2)
   int expect_solves = 0;            // announced by the caller (model-selection grids)
   std::vector<int32_t> last_order;  // work list of the most recent solve
   Buf ws_order, ws_cnt, ws_off, ws_stat_i, ws_stat_l, ws_stat_f, ws_misc, ws_arena_i, ws_arena_v,
@@ -466,7 +474,8 @@ void destroy(slimgpu_matrix* m) {
        {&m->ws_order, &m->ws_cnt, &m->ws_off, &m->ws_stat_i, &m->ws_stat_l, &m->ws_stat_f,
         &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_xslab, &m->ws_ulist,
         &m->ws_trace, &m->ws_mailbox, &m->ws_part, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval,
-        &m->ws_gram, &m->ws_G, &m->ws_nunion})
+        &m->ws_gram, &m->ws_G, &m->ws_nunion, &m->ws_Glo, &m->ws_Ghi, &m->ws_Ghi2, &m->ws_hioff,
+        &m->ws_hi2off, &m->ws_hik, &m->ws_hi2k, &m->ws_rankof, &m->ws_itemof})
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -519,7 +528,6 @@ slimgpu_matrix_t* matrix_from_host(int32_t nrows, const ssize_t* rowptr, const i
     if (status) *status = SLIM_ERROR_INPUT;
     return nullptr;
   }
-  auto* m = new slimgpu_matrix();
   const double t0 = now_ms();
   // Repeated (user, item) pairs.  The reference copies them verbatim (setup.c:119-126) and then
   // treats them inconsistently -- the LAST value of a pair is the target y[u] (estimate.c:406-408),
@@ -530,6 +538,7 @@ slimgpu_matrix_t* matrix_from_host(int32_t nrows, const ssize_t* rowptr, const i
   std::vector<int64_t> mptr;
   std::vector<int32_t> mind;
   std::vector<float> mval;
+  try {  // (host vectors of nnz entries: a failed allocation is SLIM_ERROR_MEMORY, not a terminate)
   if (const char* e = std::getenv("SLIM_GPU_DUPLICATES"); e && std::strcmp(e, "sum") == 0 && nrows > 0) {
     bool any = false;
     std::vector<std::pair<int32_t, float>> row;
@@ -568,7 +577,14 @@ slimgpu_matrix_t* matrix_from_host(int32_t nrows, const ssize_t* rowptr, const i
       if (rowval) rowval = mval.data();
     }
   }
+  } catch (const std::bad_alloc&) {
+    set_error("SLIMGPU_MatrixFromHost: out of host memory while merging repeated pairs");
+    if (status) *status = SLIM_ERROR_MEMORY;
+    return nullptr;
+  }
+  slimgpu_matrix* m = nullptr;
   try {
+    m = new slimgpu_matrix();
     pick_device(m, opt);
     m->nrows = nrows;
     m->nnz = rowptr[nrows];
@@ -831,6 +847,84 @@ constexpr int kBitmapBytes = 64 * 1024;  // dynamic LDS of a tile workgroup (use
 
 }  // namespace
 
+namespace {
+
+// G (floats, m->ws_G) -> byte planes in popularity order (gram_pack.hpp).  Returns false, and
+// leaves the handle on the float kernels, when G holds anything but integers in [0, 2^24)
+// (fractional or negative ratings) or the planes do not fit the free memory.
+bool pack_gram(slimgpu_matrix* m) {
+  m->Gp_tried = true;
+  if (std::getenv("SLIM_GPU_NO_GRAMR")) return false;
+  const int32_t ncols = m->ncols;
+  hipStream_t st = m->stream;
+  const double t0 = now_ms();
+  // popularity order: ratings per item descending, ties by id
+  std::vector<int64_t> cp((size_t)ncols + 1);
+  HIP_TRY(hipMemcpy(cp.data(), m->d_colptr, sizeof(int64_t) * cp.size(), hipMemcpyDeviceToHost));
+  const int32_t nchunks = (ncols + 15) / 16;
+  std::vector<int32_t> item_of((size_t)nchunks * 16, -1), rank_of((size_t)ncols);
+  std::iota(item_of.begin(), item_of.begin() + ncols, 0);
+  std::stable_sort(item_of.begin(), item_of.begin() + ncols, [&](int32_t a, int32_t b) {
+    return cp[(size_t)a + 1] - cp[(size_t)a] > cp[(size_t)b + 1] - cp[(size_t)b];
+  });
+  for (int32_t r = 0; r < ncols; ++r) rank_of[(size_t)item_of[(size_t)r]] = r;
+  int32_t* d_item_of = ws_get<int32_t>(m->ws_itemof, item_of.size());
+  int32_t* d_rank_of = ws_get<int32_t>(m->ws_rankof, rank_of.size());
+  HIP_TRY(hipMemcpyAsync(d_item_of, item_of.data(), sizeof(int32_t) * item_of.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_rank_of, rank_of.data(), sizeof(int32_t) * rank_of.size(), hipMemcpyHostToDevice, st));
+  int32_t* d_hik = ws_get<int32_t>(m->ws_hik, (size_t)ncols + 1);   // [ncols] + the flag word
+  int32_t* d_hi2k = ws_get<int32_t>(m->ws_hi2k, (size_t)ncols);
+  int32_t* d_flag = d_hik + ncols;
+  HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), st));
+  const float* dG = static_cast<const float*>(m->ws_G.p);
+  hipLaunchKernelGGL(gram_pack_scan_fn(), dim3(ncols), dim3(256), 0, st, dG, m->G_ld, ncols, d_item_of, d_hik,
+                     d_hi2k, d_flag);
+  HIP_TRY(hipGetLastError());
+  std::vector<int32_t> hk((size_t)ncols + 1), h2k((size_t)ncols);
+  HIP_TRY(hipMemcpyAsync(hk.data(), d_hik, sizeof(int32_t) * hk.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h2k.data(), d_hi2k, sizeof(int32_t) * h2k.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (hk[(size_t)ncols] != 0) return false;  // not integers in [0, 2^24): stays on the float kernels
+  std::vector<int64_t> off1((size_t)ncols), off2((size_t)ncols);
+  int64_t n1 = 0, n2 = 0;
+  for (int32_t i = 0; i < ncols; ++i) {
+    off1[(size_t)i] = n1;
+    off2[(size_t)i] = n2;
+    n1 += (int64_t)hk[(size_t)i] * kPackGroup;
+    n2 += (int64_t)h2k[(size_t)i] * kPackGroup;
+  }
+  const int64_t ldb = (int64_t)nchunks * 16;
+  // (a group of slack behind each pool: a lane outside a plane's prefix reads byte 0 of the plane)
+  const size_t need = (size_t)ncols * (size_t)ldb + (size_t)n1 + (size_t)n2 + 2 * (size_t)kPackGroup;
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  if (need + (size_t(4) << 30) > free_b + m->ws_Glo.bytes + m->ws_Ghi.bytes + m->ws_Ghi2.bytes) return false;
+  uint8_t* d_lo = ws_get<uint8_t>(m->ws_Glo, (size_t)ncols * (size_t)ldb);
+  uint8_t* d_hi = ws_get<uint8_t>(m->ws_Ghi, (size_t)n1 + kPackGroup);
+  uint8_t* d_hi2 = ws_get<uint8_t>(m->ws_Ghi2, (size_t)n2 + kPackGroup);
+  int64_t* d_off1 = ws_get<int64_t>(m->ws_hioff, (size_t)ncols);
+  int64_t* d_off2 = ws_get<int64_t>(m->ws_hi2off, (size_t)ncols);
+  HIP_TRY(hipMemcpyAsync(d_off1, off1.data(), sizeof(int64_t) * off1.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_off2, off2.data(), sizeof(int64_t) * off2.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(d_hi + n1, 0, kPackGroup, st));
+  HIP_TRY(hipMemsetAsync(d_hi2 + n2, 0, kPackGroup, st));
+  hipLaunchKernelGGL(gram_pack_write_fn(), dim3(ncols), dim3(256), 0, st, dG, m->G_ld, ncols, d_item_of, nchunks,
+                     d_lo, ldb, d_hi, d_off1, d_hik, d_hi2, d_off2, d_hi2k);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));  // (off1 / off2 are locals)
+  m->Gp_ldb = ldb;
+  m->Gp_nchunks = nchunks;
+  m->Gp_bytes_per_row = (double)ldb + (double)(n1 + n2) / std::max(1, ncols);
+  m->Gp_ready = true;
+  if (const char* te = std::getenv("SLIM_GPU_TRACE"); te && std::atoi(te) >= 1)
+    std::fprintf(stderr, "[trace] G packed: lo %.2f GB + hi %.2f GB + hi2 %.3f GB = %.3f bytes per entry, %.1f ms\n",
+                 (double)ncols * ldb * 1e-9, n1 * 1e-9, n2 * 1e-9,
+                 m->Gp_bytes_per_row / std::max(1, ncols), now_ms() - t0);
+  return true;
+}
+
+}  // namespace
+
 slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
                      int32_t* status, const int32_t* columns, int32_t ncolumns, bool row_view) {
   const double t_begin = now_ms();
@@ -924,20 +1018,29 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       use_gram = true;
     } else if (kernel == SLIMGPU_KERNEL_AUTO && gram_fits && lds_need > 64 * 1024 &&
                !std::getenv("SLIM_GPU_NO_GRAMCD")) {
-      // (G serves every column and costs a screen pass over all of them: not for a grid over a
-      // small part of the matrix unless it is there already)
-      bool repeated = m->G_ready ||
-                      ((int64_t)nwork * 4 >= ncols &&
-                       (m->expect_solves >= 2 || (!m->last_order.empty() && m->last_order == order)));
-      // SLIM_GPU_GRAMCD=first: also for a FIRST solve when the byte model says item space wins --
-      // most columns requested (G serves every column; building it costs about one tenth of a
-      // residual sweep) and columns long against the item count (an update moves 4 ncols bytes
-      // there, ~128 nnz(col) bytes for one changed problem of a tile here).  Measured: C5 cold
-      // 158 -> 10 s, C4 whole matrix 579 -> 133 s; C4 at 0.1 % density stays with the tile kernel.
-      if (const char* e = std::getenv("SLIM_GPU_GRAMCD"); e && std::strcmp(e, "first") == 0)
-        repeated = repeated || ((int64_t)nwork * 2 >= ncols &&
-                                (double)m->nnz * 32.0 >= (double)ncols * (double)ncols);
-      if (repeated) {
+      // The engine's own choice between the residual (tile) kernel and item space, by their byte
+      // models per problem and sweep: the tile kernel moves ~5.4 bytes per nnz of
+      // R (ids + one residual line per nnz shared by 32 problems, write-backs), item space one
+      // row of G per update -- f ncols rows of 4 ncols bytes with f ~ 3 % of the coordinates
+      // carrying a coefficient (C4 2.6 %, C4 at 0.1 % 2.7 %, ml100k 2.4 %).  rho = item / tile
+      // = (ncols^2 / nnz) / 45; measured 0.22 on C4 (1.3 against 5.8 ms per column), 2.6 on C4 at
+      // 0.1 % density.  G itself costs what ~ncols / 32 columns cost the tile kernel (one screen
+      // pass over every column; measured ncols / 64 on C4, ncols / 36 on C5), so a FIRST solve
+      // takes item space when the columns it solves -- times the number of solves the caller
+      // announced (SLIMGPU_MatrixExpectSolves: a model-selection grid) -- save more than that;
+      // with G already there the per-column figure decides alone.  A shard of a multi-GPU solve
+      // applies the rule to its own columns (every replica builds its own G).  Deterministic in
+      // the call's arguments and the handle's state (G built or not): the same call on a fresh
+      // handle always takes the same kernel.
+      const double rho = (double)ncols * (double)ncols / std::max(1.0, (double)m->nnz) / 45.0;
+      const double solves = (double)std::max(1, m->expect_solves);
+      // (explicit cluster / heavy-phase options describe a residual-kernel launch: honoured)
+      const bool tile_geometry_asked = opt.cluster != 0 || opt.heavy_tiles >= 0 || opt.heavy_cluster != 0;
+      bool item_space = rho < 1.0 && !tile_geometry_asked &&
+                        (m->G_ready || (double)nwork * solves * (1.0 - rho) > (double)ncols / 32.0);
+      if (const char* e = std::getenv("SLIM_GPU_GRAMCD"); e && std::strcmp(e, "never-first") == 0)
+        item_space = item_space && (m->G_ready || m->expect_solves >= 2);  // (round-4 policy, A/B runs)
+      if (item_space) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         use_gram = m->G_ready || G_bytes + (size_t(8) << 30) <= free_b + m->ws_gram.bytes;
@@ -967,6 +1070,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       if (!none) return fail(bst);
       csr_free(none);
       m->G_ready = true;
+      m->Gp_ready = false;
+      m->Gp_tried = false;
+      if (!pack_gram(m)) m->Gp_ready = false;
       m->G_build_ms = now_ms() - tb;
       if (const char* te = std::getenv("SLIM_GPU_TRACE"); te && std::atoi(te) >= 1)
         std::fprintf(stderr, "[trace] G = R^T R (%d x %d, %.2f GB) built in %.1f ms\n", ncols, ncols,
@@ -985,7 +1091,20 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     const bool use_lds = kernel == SLIMGPU_KERNEL_WAVE_LDS;
     if (use_gram && gram_v == 0)  // g in HBM: 8 or 16 wavefronts per workgroup
       if (const char* e = std::getenv("SLIM_GPU_GRAM_NW")) gram_nw = std::atoi(e) == 8 ? 8 : 16;
-    const size_t gram_lds = gram_v > 0 ? sizeof(float) * (size_t)ncols_pad : 0;
+    // item space with g on chip and G as byte planes (cd_gramr.hpp) whenever G could be packed and
+    // the items fit the largest instantiation (106 496); SLIM_GPU_NO_GRAMR=1: the float kernels
+    GramrFn fn_r = nullptr;
+    int gramr_kr = 0, gramr_kl = 0;
+    if (use_gram && m->G_ready && !m->Gp_tried) (void)pack_gram(m);
+    if (use_gram && m->Gp_ready && !std::getenv("SLIM_GPU_NO_GRAMR"))
+      fn_r = gramr_kernel(m->Gp_nchunks, &gramr_kr, &gramr_kl);
+    const bool use_gramr = fn_r != nullptr;
+    if (use_gramr) {
+      gram_nw = kGramrNT / 64;
+      gram_v = 1;  // (x only in the slab: g is on chip)
+    }
+    const size_t gram_lds = use_gramr ? sizeof(float) * (size_t)gramr_kl * kPackGroup
+                                      : (gram_v > 0 ? sizeof(float) * (size_t)ncols_pad : 0);
     // tile width: 32 item columns per workgroup (128-byte residual lines) unless the row
     // offsets would overflow the kernel's 32-bit byte offsets
     int tileP = kernel == SLIMGPU_KERNEL_TILE16 ? 16 : 32;
@@ -1052,10 +1171,9 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int waves_per_cu;
     if (use_gram) {  // one workgroup per problem, as many per CU as g (LDS) and registers allow
       int per_cu = 0;
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds));
-      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn),
-                                                           64 * gram_nw, gram_lds));
+      const void* kfn = use_gramr ? reinterpret_cast<const void*>(fn_r) : reinterpret_cast<const void*>(fn);
+      HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds));
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * gram_nw, gram_lds));
       if (per_cu < 1) {
         set_error("SLIMGPU_Learn: the item-space kernel does not fit a compute unit of this device");
         return fail(SLIM_ERROR);
@@ -1185,7 +1303,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int32_t* d_cnt = ws_get<int32_t>(m->ws_cnt, (size_t)ncols);
     int64_t* d_off = ws_get<int64_t>(m->ws_off, (size_t)ncols);
     int32_t* d_sti = ws_get<int32_t>(m->ws_stat_i, 3 * (size_t)ncols);
-    int64_t* d_stl = ws_get<int64_t>(m->ws_stat_l, 3 * (size_t)ncols);
+    int64_t* d_stl = ws_get<int64_t>(m->ws_stat_l, 4 * (size_t)ncols);
     float* d_stf = ws_get<float>(m->ws_stat_f, 2 * (size_t)ncols);
     // misc: [0] queue (int32) [1] overflow (int32) [2..3] cursor (u64)
     int32_t* d_misc = ws_get<int32_t>(m->ws_misc, 16);  // [4] queue of the heavy phase
@@ -1271,7 +1389,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (size_t)ncols, stream));
     HIP_TRY(hipMemsetAsync(d_off, 0, sizeof(int64_t) * (size_t)ncols, stream));
     HIP_TRY(hipMemsetAsync(d_sti, 0, sizeof(int32_t) * 3 * (size_t)ncols, stream));
-    HIP_TRY(hipMemsetAsync(d_stl, 0, sizeof(int64_t) * 3 * (size_t)ncols, stream));
+    HIP_TRY(hipMemsetAsync(d_stl, 0, sizeof(int64_t) * 4 * (size_t)ncols, stream));
     HIP_TRY(hipMemsetAsync(d_stf, 0, sizeof(float) * 2 * (size_t)ncols, stream));
 
     DevMatrix A;
@@ -1340,6 +1458,12 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       const int32_t npend = (int32_t)pending.size();
       int32_t* d_ai = ws_get<int32_t>(m->ws_arena_i, (size_t)arena_cap, m);
       float* d_av = ws_get<float>(m->ws_arena_v, (size_t)arena_cap, m);
+      if (gram_mode != 0 && m->ws_gram.p != d_gram) {
+        // the arena did not fit next to the screen-sum cache and ws_get gave the cache up
+        // (drop_screen_cache): this launch neither records nor reads it
+        gram_mode = 0;
+        d_gram = nullptr;
+      }
       HIP_TRY(hipMemcpyAsync(d_order, pending.data(), sizeof(int32_t) * (size_t)npend,
                              hipMemcpyHostToDevice, stream));
       HIP_TRY(hipMemsetAsync(d_misc, 0, sizeof(int32_t) * 16, stream));
@@ -1446,6 +1570,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.st_G = d_stl;
       S.st_D = d_stl + ncols;
       S.st_U = d_stl + 2 * (size_t)ncols;
+      S.st_B = d_stl + 3 * (size_t)ncols;
       S.st_err = d_stf;
       S.st_obj = d_stf + ncols;
 
@@ -1453,7 +1578,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       const int launch_waves =
           use_tile ? std::max(1, std::min((npend + tileP - 1) / tileP, nclusters)) * clusterK
                    : std::max(1, std::min(npend, nwaves));
-      if (use_gram)  // the union of the active sets of every tile, read off G
+      HIP_TRY(hipEventRecord(ev0, stream));
+      if (use_gram)  // the union of the active sets of every tile, read off G (inside kernel_ms)
         hipLaunchKernelGGL(gram_union_fn(), dim3(S.ngroups), dim3(64), 0, stream, A, S);
       // the heavy phase needs at least one whole big cluster in the launch
       if (S.nheavy > 0 && launch_waves < clusterHi) S.nheavy = 0;
@@ -1477,7 +1603,21 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         S.xcd_swizzle = 1;
         if (const char* e = std::getenv("SLIM_GPU_XCD")) S.xcd_swizzle = std::atoi(e) != 0;
       }
-      HIP_TRY(hipEventRecord(ev0, stream));
+      if (use_gramr) {
+        GramPacked P;
+        P.lo = static_cast<const uint8_t*>(m->ws_Glo.p);
+        P.ldb = m->Gp_ldb;
+        P.hi = static_cast<const uint8_t*>(m->ws_Ghi.p);
+        P.hi_off = static_cast<const int64_t*>(m->ws_hioff.p);
+        P.hi_k = static_cast<const int32_t*>(m->ws_hik.p);
+        P.hi2 = static_cast<const uint8_t*>(m->ws_Ghi2.p);
+        P.hi2_off = static_cast<const int64_t*>(m->ws_hi2off.p);
+        P.hi2_k = static_cast<const int32_t*>(m->ws_hi2k.p);
+        P.rank_of = static_cast<const int32_t*>(m->ws_rankof.p);
+        P.item_of = static_cast<const int32_t*>(m->ws_itemof.p);
+        P.nchunks = m->Gp_nchunks;
+        hipLaunchKernelGGL(fn_r, dim3(launch_now), dim3(kGramrNT), gram_lds, stream, A, S, P);
+      } else
       hipLaunchKernelGGL(fn, dim3(launch_now),
                          dim3(use_gram ? 64 * gram_nw : (use_tile ? 64 * tileNW : 64)),
                          use_gram ? gram_lds : (use_lds ? lds_need : (use_tile ? tile_lds : 0)),
@@ -1620,8 +1760,17 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     HIP_TRY(hipMemcpy(cs.conv.data(), d_sti + 2 * (size_t)ncols, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(cs.G.data(), d_stl, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
     int64_t gram_rows = 0;  // item-space kernel: rows of G it read (its byte model)
-    if (use_gram)
+    double gram_bytes = 0;
+    if (use_gram) {
       for (int32_t c : requested) gram_rows += cs.G[(size_t)c];
+      if (use_gramr) {  // packed rows: the bytes each column's updates streamed, counted on the device
+        std::vector<int64_t> hb((size_t)ncols);
+        HIP_TRY(hipMemcpy(hb.data(), d_stl + 3 * (size_t)ncols, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
+        for (int32_t c : requested) gram_bytes += (double)hb[(size_t)c];
+      } else {
+        gram_bytes = (double)gram_rows * 4.0 * (double)ncols_pad;
+      }
+    }
     if (use_tile || use_gram)  // the Gram work of a column is the staging pass's cost figure
       for (int32_t c : requested) cs.G[(size_t)c] = m->h_cost[(size_t)c];
     HIP_TRY(hipMemcpy(cs.D.data(), d_stl + ncols, sizeof(int64_t) * (size_t)ncols, hipMemcpyDeviceToHost));
@@ -1729,7 +1878,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     st.gather_ms = now_ms() - t_kernel_done;
     st.gram_build_ms = use_gram ? m->G_build_ms : 0.0;
     st.gram_rows = gram_rows;
-    st.gram_bytes = use_gram ? (double)gram_rows * 4.0 * (double)ncols_pad : 0.0;
+    st.gram_bytes = gram_bytes;
     if (use_gram) m->G_build_ms = 0.0;  // (charged to the solve that paid for it)
     if (!opt.build_G) m->last_order = requested;
     st.total_ms = now_ms() - t_begin;

@@ -1,0 +1,159 @@
+// gram_pack.hpp -- G = R^T R as byte planes (the form the item-space kernel of cd_gramr.hpp streams).
+//
+// An update of item-space CD reads one row of G (cd_gram.hpp): 4 ncols bytes as floats.  For a
+// binary or small-integer rating matrix every entry of G is a non-negative integer below 2^24
+// (a co-rating count, or a sum of products of small integers) and most of them are small:
+// G_ij ~ nnz_i nnz_j / nrows, so in a row only the columns of the most popular items reach 256
+// (C4: ~10 % of an average row; nothing reaches 65 536 outside the 160 x 160 block of the top
+// items).  The packed form stores a row as
+//
+//     lo [ncols]      bits 0..7 of every entry, columns in POPULARITY order (rank 0 = the item
+//                     with the most ratings, ties by id)
+//     hi [hi_k 8192]  bits 8..15 of the first hi_k groups of 8192 ranks -- behind the last rank of
+//                     the row that needs them the plane simply ends
+//     hi2[hi2_k 8192] bits 16..23, likewise
+//
+// i.e. ~1.1-1.2 bytes per entry instead of 4, decoded exactly: (float)(lo + 256 hi + 65536 hi2)
+// is the float the unpacked G holds, so a kernel that reads the planes performs the very fmaf
+// sequence a kernel that reads the floats performs.  A matrix whose G holds anything else
+// (fractional or negative ratings) is not packed and stays with the float kernels.
+//
+// Ranks (not ids) index the planes' columns and the kernel's g vector; rank_of / item_of
+// translate.  Groups of 8192 ranks = 512 threads x 16 bytes: the unit in which cd_gramr.hpp's
+// workgroup walks a row.
+#pragma once
+#include <cstdint>
+
+#include "cd_wave.hpp"
+
+namespace slimamd {
+
+constexpr int kGramrNT = 512;     // threads of cd_gramr.hpp's workgroup
+constexpr int kPackGroup = 8192;  // ranks per group: 512 threads x one 16-byte load
+
+struct GramPacked {
+  const uint8_t* lo;       // [ncols][ldb]
+  int64_t ldb;             // bytes per row of lo: ncols rounded up to 16
+  const uint8_t* hi;       // pool of hi planes, row i at hi_off[i], hi_k[i] * 8192 bytes
+  const int64_t* hi_off;
+  const int32_t* hi_k;
+  const uint8_t* hi2;
+  const int64_t* hi2_off;
+  const int32_t* hi2_k;
+  const int32_t* rank_of;  // [ncols]
+  const int32_t* item_of;  // [nchunks * 16]; -1 behind ncols
+  int32_t nchunks;         // 16-rank chunks of a row: ceil(ncols / 16)
+};
+
+#ifdef SLIM_GRAM_PACK_KERNELS  // (defined by the one translation unit that owns the two kernels)
+// Pass 1, one workgroup per row: how many groups need the hi / hi2 plane, and whether the row can
+// be packed at all (flags[0] |= 1 otherwise).
+__global__ __launch_bounds__(256) void gram_pack_scan(const float* __restrict__ G, int64_t ld, int ncols,
+                                                      const int32_t* __restrict__ item_of,
+                                                      int32_t* __restrict__ hi_k, int32_t* __restrict__ hi2_k,
+                                                      int32_t* __restrict__ flags) {
+  const int row = blockIdx.x;
+  const float* __restrict__ g = G + (int64_t)row * ld;
+  int last1 = -1, last2 = -1;
+  bool bad = false;
+  for (int r = threadIdx.x; r < ncols; r += 256) {
+    const float v = g[item_of[r]];
+    const int iv = (int)v;
+    if (!(v >= 0.0f && v < 16777216.0f) || (float)iv != v) bad = true;
+    if (iv >= 256) last1 = r;
+    if (iv >= 65536) last2 = r;
+  }
+  __shared__ int s1, s2, sb;
+  if (threadIdx.x == 0) {
+    s1 = -1;
+    s2 = -1;
+    sb = 0;
+  }
+  __syncthreads();
+  atomicMax(&s1, last1);
+  atomicMax(&s2, last2);
+  if (bad) atomicOr(&sb, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    hi_k[row] = (s1 + kPackGroup) / kPackGroup;   // ceil((s1 + 1) / 8192); 0 when s1 == -1
+    hi2_k[row] = (s2 + kPackGroup) / kPackGroup;
+    if (sb) atomicOr(flags, 1);
+  }
+}
+
+// Pass 2, one workgroup per row: write the planes (16 ranks per thread and step).
+__global__ __launch_bounds__(256) void gram_pack_write(const float* __restrict__ G, int64_t ld, int ncols,
+                                                       const int32_t* __restrict__ item_of, int nchunks,
+                                                       uint8_t* __restrict__ lo, int64_t ldb,
+                                                       uint8_t* __restrict__ hi, const int64_t* __restrict__ hi_off,
+                                                       const int32_t* __restrict__ hi_k,
+                                                       uint8_t* __restrict__ hi2, const int64_t* __restrict__ hi2_off,
+                                                       const int32_t* __restrict__ hi2_k) {
+  const int row = blockIdx.x;
+  const float* __restrict__ g = G + (int64_t)row * ld;
+  const int n1 = hi_k[row] * (kPackGroup / 16), n2 = hi2_k[row] * (kPackGroup / 16);
+  uint8_t* __restrict__ plo = lo + (int64_t)row * ldb;
+  uint8_t* __restrict__ phi = hi + hi_off[row];
+  uint8_t* __restrict__ ph2 = hi2 + hi2_off[row];
+  const int nmax = max(nchunks, max(n1, n2));
+  for (int c = threadIdx.x; c < nmax; c += 256) {
+    uint32_t w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0};
+    if (c < nchunks) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int it = item_of[c * 16 + e];
+        const uint32_t iv = it >= 0 ? (uint32_t)(int)g[it] : 0u;
+        w0[e >> 2] |= (iv & 255u) << (8 * (e & 3));
+        w1[e >> 2] |= ((iv >> 8) & 255u) << (8 * (e & 3));
+        w2[e >> 2] |= ((iv >> 16) & 255u) << (8 * (e & 3));
+      }
+      *reinterpret_cast<uint4*>(plo + 16 * (int64_t)c) = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+    }
+    if (c < n1) *reinterpret_cast<uint4*>(phi + 16 * (int64_t)c) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+    if (c < n2) *reinterpret_cast<uint4*>(ph2 + 16 * (int64_t)c) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+  }
+}
+
+#endif  // SLIM_GRAM_PACK_KERNELS
+
+// the 16 floats of one chunk: lo + 256 hi + 65536 hi2, exact (integers below 2^24)
+__device__ __forceinline__ void unpack16(const uint4 l, float (&f)[16]) {
+  const uint32_t w[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[4 * j + 0] = (float)(w[j] & 255u);
+    f[4 * j + 1] = (float)((w[j] >> 8) & 255u);
+    f[4 * j + 2] = (float)((w[j] >> 16) & 255u);
+    f[4 * j + 3] = (float)(w[j] >> 24);
+  }
+}
+__device__ __forceinline__ void unpack16_add(const uint4 h, const float scale, float (&f)[16]) {
+  const uint32_t w[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[4 * j + 0] = fmaf(scale, (float)(w[j] & 255u), f[4 * j + 0]);
+    f[4 * j + 1] = fmaf(scale, (float)((w[j] >> 8) & 255u), f[4 * j + 1]);
+    f[4 * j + 2] = fmaf(scale, (float)((w[j] >> 16) & 255u), f[4 * j + 2]);
+    f[4 * j + 3] = fmaf(scale, (float)(w[j] >> 24), f[4 * j + 3]);
+  }
+}
+
+// one entry: G[row][rank]
+__device__ __forceinline__ float packed_entry(const GramPacked& P, const int row, const int hk, const int h2k,
+                                              const uint8_t* __restrict__ plo, const uint8_t* __restrict__ phi,
+                                              const uint8_t* __restrict__ ph2, const int rank) {
+  float f = (float)plo[rank];
+  if (hk > 0) {  // (uniform branch; lanes behind the prefix read entry 0 and drop it)
+    const bool in1 = rank < hk * kPackGroup;
+    const float h = (float)phi[in1 ? rank : 0];
+    f = in1 ? fmaf(256.0f, h, f) : f;
+    if (h2k > 0) {
+      const bool in2 = rank < h2k * kPackGroup;
+      const float h2 = (float)ph2[in2 ? rank : 0];
+      f = in2 ? fmaf(65536.0f, h2, f) : f;
+    }
+  }
+  return f;
+}
+
+}  // namespace slimamd

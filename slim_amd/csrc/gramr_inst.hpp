@@ -1,0 +1,22 @@
+// gramr_inst.hpp -- the instantiations of cd_gramr_kernel (cd_gramr.hpp) and the packing kernels
+// (gram_pack.hpp); engine.hip picks one through gramr_kernel().
+#pragma once
+#include "gram_pack.hpp"
+#include "tile_inst.hpp"
+
+namespace slimamd {
+
+using GramrFn = void (*)(const DevMatrix, const SolveArgs, const GramPacked);
+
+// the smallest instantiation whose K = KR + KL groups of 8192 ranks cover nchunks 16-rank chunks
+// (nullptr: more items than the largest one holds on chip -- 106 496)
+GramrFn gramr_kernel(int nchunks, int* kr, int* kl);
+GramrFn gramr_kernel_k13();  // <10, 3>: its own translation unit (compiles beside the others)
+
+using PackScanFn = void (*)(const float*, int64_t, int, const int32_t*, int32_t*, int32_t*, int32_t*);
+using PackWriteFn = void (*)(const float*, int64_t, int, const int32_t*, int, uint8_t*, int64_t, uint8_t*,
+                             const int64_t*, const int32_t*, uint8_t*, const int64_t*, const int32_t*);
+PackScanFn gram_pack_scan_fn();
+PackWriteFn gram_pack_write_fn();
+
+}  // namespace slimamd

@@ -1,0 +1,6 @@
+// cd_gramr_kernel<10, 3>: up to 106 496 items (the 1M x 100K configuration); see gramr_inst.hpp
+#include "cd_gramr.hpp"
+#include "gramr_inst.hpp"
+namespace slimamd {
+GramrFn gramr_kernel_k13() { return cd_gramr_kernel<10, 3>; }
+}  // namespace slimamd

@@ -46,55 +46,89 @@ def _batch_tiles(mat, begin, batch):
     return cols[np.argsort(-cost[cols], kind="stable")].astype(np.int32).reshape(-1, 32)
 
 
-def _check_tile(mat, R, tile, threads, **geom):
+def _check_tile(mat, R, tile, threads, geoms=({},)):
+    """One whole tile through the C ABI, once per entry of `geoms` (kernel / cluster options), each
+    against ONE oracle walk of the same tile in the same visiting order."""
     kw = dict(l1r=1.0, l2r=1.0, optTol=1e-7)
-    W, st = mat.learn(columns=tile, niters=10000, seed=1, **kw, **geom)
-    cs = mat.column_stats()
     Wo, so, _, _ = O.learn_cd_tile(R, tileP=32, order=tile, maxniters=10000, seed=1,
                                    nthreads=threads, binary=True, return_stats=True, **kw)
-    assert W[:, tile].nnz > 0 and W.nnz == W[:, tile].nnz
-    assert np.array_equal(cs.nacols[tile], so["nacols"][tile])      # identical active sets
-    assert np.array_equal(cs.G[tile], so["G"][tile])
-    assert (cs.sweeps[tile] == so["sweeps"][tile]).mean() >= 0.98   # identical sweep counts
-    assert maxdiff(W[:, tile], Wo[:, tile]) <= 2e-5                 # stated fp32 tolerance
-    return W, Wo, st
+    out = []
+    for geom in geoms:
+        W, st = mat.learn(columns=tile, niters=10000, seed=1, **kw, **geom)
+        cs = mat.column_stats()
+        assert W[:, tile].nnz > 0 and W.nnz == W[:, tile].nnz
+        assert np.array_equal(cs.nacols[tile], so["nacols"][tile])      # identical active sets
+        assert np.array_equal(cs.G[tile], so["G"][tile])
+        assert (cs.sweeps[tile] == so["sweeps"][tile]).mean() >= 0.98   # identical sweep counts
+        assert maxdiff(W[:, tile], Wo[:, tile]) <= 2e-5                 # stated fp32 tolerance
+        out.append((W, st))
+    return out, Wo
 
 
-def _check_tile_tight(mat, R, tile, threads):
-    """at optTol 1e-12 the visiting order no longer matters -- the tile kernel
+def _check_tile_tight(mat, R, tile, threads, geoms=({},)):
+    """at optTol 1e-12 the visiting order no longer matters -- the kernels
     against the oracle in its own per-item order (reference arithmetic), <= 2e-5."""
     kt = dict(l1r=1.0, l2r=1.0, optTol=1e-12)
-    Wt, _ = mat.learn(columns=tile, niters=100000, seed=1, **kt)
     Wp = O.learn_cd(R, cols=tile, order=O.ORDER_PERM, seed=1, aty=O.ATY_GRAM, maxniters=100000,
                     nthreads=threads, binary=True, chunk=1, **kt)
-    assert maxdiff(Wt[:, tile], Wp[:, tile]) <= 2e-5                # observed 2.6e-8 / 1.0e-7
+    for geom in geoms:
+        Wt, _ = mat.learn(columns=tile, niters=100000, seed=1, **kt, **geom)
+        assert maxdiff(Wt[:, tile], Wp[:, tile]) <= 2e-5            # observed 2.6e-8 / 1.0e-7
 
 
-@pytest.mark.timeout(900, method="thread")
+@pytest.mark.timeout(1500, method="thread")
 def test_c4_full_size_tiles_match_oracle_in_tile_order():
-    """C4, seed 1: the median tile of the benchmark's first step, the tile holding the first column
-    bench.py's cpu_baseline samples, and -- so that the heavy phase and clusters of 16 are in
-    play -- the same tiles once more as a two-tile launch with a heavy phase."""
+    """C4, seed 1.  (1) The product default: SLIMGPU_Learn with default options over the
+    benchmark's first step (8192 columns) on a fresh handle -- the engine's own choice must be
+    item space (G = R^T R of all 100 000 items built inside the call, cd_gram*.hpp), and its
+    median tile is compared with the oracle walking that tile of that work list.  (2) Whole
+    tiles through SLIMGPU_LearnColumns on BOTH paths (residual kernel, item-space kernel) against
+    one oracle walk each: the median tile of the step and the tile holding the first column
+    bench.py's cpu_baseline samples; the optTol 1e-12 check on both paths; and -- so that the
+    heavy phase and clusters of 16 are in play -- the same tiles once more as a two-tile launch
+    of the residual kernel with a heavy phase."""
     mat, R = _stage("c4")
     O.cache_setup(True)           # one transpose of R for the oracle calls of this test
     threads = min(32, O.max_threads())
     tiles = _batch_tiles(mat, 0, 8192)   # bench.py DEFAULT_BATCH
+    kw = dict(l1r=1.0, l2r=1.0, optTol=1e-7)
+    # (0) a first solve of ONE tile: G would never pay for itself -- the engine stays in user space
+    _, st0 = mat.learn(columns=tiles[len(tiles) // 2], niters=10000, seed=1, **kw)
+    assert st0["kernel"] == KERNEL_TILE
+    # (1) default options, the benchmark's step
+    Wd, std = mat.learn(col_begin=0, col_end=8192, niters=10000, seed=1, **kw)
+    csd = mat.column_stats()
+    assert std["kernel"] == KERNEL_GRAM and std["gram_build_ms"] > 0
+    k = len(tiles) // 2
+    Wk, sk, _, _ = O.learn_cd_tile(R, tileP=32, order=tiles.reshape(-1), tiles=(k, 1), maxniters=10000,
+                                   seed=1, nthreads=threads, binary=True, return_stats=True, **kw)
+    tk = tiles[k]
+    assert np.array_equal(csd.nacols[tk], sk["nacols"][tk])
+    assert (csd.sweeps[tk] == sk["sweeps"][tk]).mean() >= 0.98
+    assert maxdiff(Wd[:, tk], Wk[:, tk]) <= 2e-5
+    # (2) whole tiles on both paths
     rng = np.random.default_rng(1)
     c0 = int(np.sort(rng.permutation(8192)[:8])[0])
     sampled = int(np.where(tiles == c0)[0][0])
     picked = [tiles[len(tiles) // 2], tiles[sampled]]
-    results = [_check_tile(mat, R, t, threads) for t in picked]      # one tile: clusters of 16
-    _check_tile_tight(mat, R, picked[0], threads)
+    both_paths = (dict(kernel=KERNEL_TILE), dict(kernel=KERNEL_GRAM))
+    for t in picked:                                    # one tile: clusters of 16 (residual kernel)
+        (pair, _) = _check_tile(mat, R, t, threads, geoms=both_paths)
+        assert pair[0][1]["kernel"] == KERNEL_TILE and pair[1][1]["kernel"] == KERNEL_GRAM
+        assert maxdiff(pair[0][0][:, t], pair[1][0][:, t]) <= 2e-5
+    _check_tile_tight(mat, R, picked[0], threads, geoms=both_paths)
     # both tiles in one launch, the first one as a "heavy" tile on a cluster of 16, the second
     # on clusters of 4: the per-problem arithmetic and the visiting order may not depend on it
     both = np.concatenate(picked)
     cost = mat.column_cost()
     order = both[np.argsort(-cost[both], kind="stable")]
-    W2, _ = mat.learn(columns=both, l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=1,
-                      cluster=4, heavy_tiles=1, heavy_cluster=16)
+    W2, _ = mat.learn(columns=both, niters=10000, seed=1, kernel=KERNEL_TILE,
+                      cluster=4, heavy_tiles=1, heavy_cluster=16, **kw)
     Wo2 = O.learn_cd_tile(R, tileP=32, order=order, maxniters=10000, seed=1, nthreads=threads,
-                          binary=True, l1r=1.0, l2r=1.0, optTol=1e-7)
+                          binary=True, **kw)
     assert maxdiff(W2[:, both], Wo2[:, both]) <= 2e-5
+    Wg2, _ = mat.learn(columns=both, niters=10000, seed=1, kernel=KERNEL_GRAM, **kw)
+    assert maxdiff(Wg2[:, both], Wo2[:, both]) <= 2e-5
     O.cache_setup(False)
     mat.close()
 
@@ -106,8 +140,8 @@ def test_c5_full_size_tile_matches_oracle_in_tile_order():
     threads = min(32, O.max_threads())
     tiles = _batch_tiles(mat, 0, 4096)
     O.cache_setup(True)
-    _check_tile(mat, R, tiles[len(tiles) // 2], threads)
-    _check_tile_tight(mat, R, tiles[len(tiles) // 2], threads)
+    _check_tile(mat, R, tiles[len(tiles) // 2], threads, geoms=(dict(kernel=KERNEL_TILE),))
+    _check_tile_tight(mat, R, tiles[len(tiles) // 2], threads, geoms=(dict(kernel=KERNEL_TILE),))
     O.cache_setup(False)
     mat.close()
 

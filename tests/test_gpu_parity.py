@@ -553,30 +553,45 @@ def test_gram_kernel_warm_start_matches_oracle_tile_walk():
         m.close()
 
 
-def test_gram_kernel_is_chosen_for_repeated_solves_only(monkeypatch):
-    """KERNEL_AUTO: the tile kernel for a first solve; item-space CD once the same columns come
-    again, or at once when the caller announced a grid (SLIMGPU_MatrixExpectSolves, what
-    Py_SLIM_Mselect / slim_mselect do); never for FSLIM; SLIM_GPU_NO_GRAMCD=1 turns it off."""
+def test_automatic_kernel_choice_follows_the_byte_model(monkeypatch):
+    """KERNEL_AUTO (engine.hip): item space when its byte model beats the residual
+    kernel's -- rho = (ncols^2 / nnz) / 45 < 1 -- and the columns of the call (times the solves a
+    caller announced, SLIMGPU_MatrixExpectSolves: what Py_SLIM_Mselect / slim_mselect do) pay for
+    G = R^T R, or G is there already; never for FSLIM, never against explicit residual-kernel
+    geometry options; SLIM_GPU_NO_GRAMCD=1 turns it off; deterministic on a fresh handle."""
     R = _random_ratings(40000, 3000, 0.004, 5)      # 4 * (40000 + 2 * 3008) > 64 KiB: no LDS kernel
-    m = DeviceMatrix.from_scipy(R)
-    W1, s1 = m.learn(seed=2)
-    assert s1["kernel"] == KERNEL_TILE
-    W2, s2 = m.learn(seed=2, l2r=0.5)               # the same work list again: a grid is under way
-    assert s2["kernel"] == KERNEL_GRAM and s2["gram_build_ms"] > 0
+    m = DeviceMatrix.from_scipy(R)                  # rho = (9e6 / 4.8e5) / 45 = 0.42
+    cols = np.arange(32, dtype=np.int32)
+    W0, s0 = m.learn(seed=2, columns=cols)          # one tile: 32 * 0.58 columns do not pay for G
+    assert s0["kernel"] == KERNEL_TILE
+    W1, s1 = m.learn(seed=2)                        # the whole matrix, first solve: item space
+    assert s1["kernel"] == KERNEL_GRAM and s1["gram_build_ms"] > 0
+    Wt, st = m.learn(seed=2, kernel=KERNEL_TILE)
+    assert maxdiff(W1, Wt) <= 5e-5
+    W2, s2 = m.learn(seed=2, columns=cols)          # G is there now: the per-column figure decides
+    assert s2["kernel"] == KERNEL_GRAM and s2["gram_build_ms"] == 0
     W3, s3 = m.learn(seed=2, l2r=0.5, nnbrs=20)     # FSLIM stays on the tile kernel
     assert s3["kernel"] == KERNEL_TILE
+    assert m.learn(seed=2, cluster=2)[1]["kernel"] == KERNEL_TILE   # residual-kernel geometry asked for
     with pytest.raises(RuntimeError):
         m.learn(seed=2, kernel=KERNEL_GRAM, nnbrs=20)
     m.close()
     m = DeviceMatrix.from_scipy(R)
-    m.expect_solves(45)
-    W4, s4 = m.learn(seed=2)
-    assert s4["kernel"] == KERNEL_GRAM and maxdiff(W4, W1) <= 5e-5
+    m.expect_solves(45)                             # a grid over one tile: 45 * 32 * 0.58 columns do pay
+    W4, s4 = m.learn(seed=2, columns=cols)
+    assert s4["kernel"] == KERNEL_GRAM and maxdiff(W4, W0) <= 5e-5
     m.close()
     monkeypatch.setenv("SLIM_GPU_NO_GRAMCD", "1")
     m = DeviceMatrix.from_scipy(R)
     m.expect_solves(45)
     assert m.learn(seed=2)[1]["kernel"] == KERNEL_TILE
+    m.close()
+    monkeypatch.delenv("SLIM_GPU_NO_GRAMCD")
+    # short columns against many items (rho = (2.25e8 / 9e5) / 45 = 5.6): the residual kernel's side
+    Rs = _random_ratings(30000, 15000, 0.002, 7)
+    m = DeviceMatrix.from_scipy(Rs)
+    m.expect_solves(45)
+    assert m.learn(seed=2, col_begin=0, col_end=256)[1]["kernel"] == KERNEL_TILE
     m.close()
 
 
@@ -617,8 +632,8 @@ def test_negative_previous_coefficients_start_at_zero(kernel):
 def test_tile_kernel_ratings_and_warm_start():
     R = _random_ratings(40000, 150, 0.01, 3)   # 4*(40000+300) > 64 KiB: no LDS kernel
     m = DeviceMatrix.from_scipy(R)
-    W, st = m.learn(l1r=1.0, l2r=1.0, seed=2)
-    assert st["kernel"] == KERNEL_TILE and st["lds_bytes"] == 0   # automatic choice
+    W, st = m.learn(l1r=1.0, l2r=1.0, seed=2, kernel=KERNEL_TILE)
+    assert st["kernel"] == KERNEL_TILE and st["lds_bytes"] == 0
     Wo, so, err, obj = O.learn_cd(R, order=O.ORDER_PERM, seed=2, aty=O.ATY_GRAM, nthreads=8,
                                   return_stats=True)
     assert maxdiff(W, Wo) <= 3e-3
@@ -630,7 +645,7 @@ def test_tile_kernel_ratings_and_warm_start():
     assert np.array_equal(cs.nacols, so["nacols"]) and np.array_equal(cs.G, so["G"])
     Wh, _ = m.learn(l1r=1.0, l2r=1.0, seed=2, kernel=KERNEL_WAVE_HBM)
     assert maxdiff(Wh, Wo) <= 5e-5           # the wave kernel walks the oracle's order
-    Wt, _ = m.learn(optTol=1e-13, niters=100000)
+    Wt, _ = m.learn(optTol=1e-13, niters=100000, kernel=KERNEL_TILE)
     Wr = O.learn_cd(R, order=O.ORDER_PERM, aty=O.ATY_GRAM, nthreads=8, optTol=1e-13,
                     maxniters=100000)
     assert maxdiff(Wt, Wr) <= 2e-5
