@@ -465,6 +465,10 @@ __global__ __launch_bounds__(kGramrNT, (KR <= 2 && KL == 0) ? 4 : 2) void cd_gra
         }
       }
       if (sweep) {
+        // (the first batch of a sweep may hold coordinates of the LAST batch of the sweep before,
+        // whose x wavefront 0 may still be writing: the header loads wait for it.  Inside a sweep
+        // the header of the next batch is loaded ahead without one -- its coordinates are others.)
+        __syncthreads();
         phase = 1;
         p0 = 0;
         dlt = 0.0f;
