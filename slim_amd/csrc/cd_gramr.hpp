@@ -86,7 +86,14 @@ __device__ __forceinline__ float gramr_sel(GramrRegs<KRA>& gr, const int k, cons
 }
 
 // KR groups of 8192 ranks in registers, KL groups in LDS (dynamic: KL * 32 KB).
-template <int KR, int KL>
+// DMA: the row is streamed into a per-wavefront LDS ring by `global_load_lds_dwordx4` (LDS-DMA: no
+// VGPR holds data in flight) kGramrAhead groups ahead of the one being decoded, instead of GRP
+// register loads per round trip.
+constexpr int kGramrAhead = 2;                       // groups requested ahead of the one consumed
+constexpr int kGramrSlots = 2 * (kGramrAhead + 1);   // 1 KB slots per wavefront: lo + hi per group
+constexpr int kGramrRingBytes = (kGramrNT / 64) * kGramrSlots * 1024;
+
+template <int KR, int KL, bool DMA = false>
 __global__ __launch_bounds__(kGramrNT, (KR <= 2 && KL == 0) ? 4 : 2) void cd_gramr_kernel(
     const DevMatrix A, const SolveArgs S, const GramPacked P) {
   constexpr int NT = kGramrNT, K = KR + KL;
@@ -123,58 +130,99 @@ __global__ __launch_bounds__(kGramrNT, (KR <= 2 && KL == 0) ? 4 : 2) void cd_gra
   // and update entries of g no visit ever reads) -- no exec masking, no 64-bit address per group.
   const uint32_t voff0 = 16u * (uint32_t)tid;
   const uint32_t vlast = 16u * (uint32_t)(nchunks - 1);
+  // s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+#define SLIM_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
+  char* const ring_w = reinterpret_cast<char*>(g_lds) + KL * kPackGroup * 4 + wave * (kGramrSlots * 1024);
   auto apply = [&](const uint8_t* __restrict__ plo, const uint8_t* __restrict__ phi,
                    const uint8_t* __restrict__ ph2, const int hk, const int h2k,
                    const float nd) __attribute__((always_inline)) {
-    constexpr int GRP = 4;
-    static_for<(K + GRP - 1) / GRP>([&](auto k0c) __attribute__((always_inline)) {
-      constexpr int k0 = decltype(k0c)::value * GRP;
-      uint4 l[GRP], h[GRP];
-      static_for<GRP>([&](auto uc) __attribute__((always_inline)) {
-        constexpr int u = decltype(uc)::value, k = k0 + u;
-        if constexpr (k < K) {
+    // one group: decoded and added to what the thread owns
+    auto consume = [&](auto kc, const uint4 lo, const uint4 hi) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      float f[16];
+      unpack16(lo, f);
+      if (k < hk) {
+        unpack16_add(hi, 256.0f, f);
+        if (k < h2k) {
           const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
-          l[u] = ld_off<uint4>(plo, vo);
-          if (k < hk) h[u] = ld_off<uint4>(phi, vo);
+          unpack16_add(ld_off<uint4>(ph2, vo), 65536.0f, f);
         }
-      });
-      __builtin_amdgcn_sched_barrier(0);  // (the loads of ONE group of GRP chunks in flight, not of all)
-      static_for<GRP>([&](auto uc) __attribute__((always_inline)) {
-        constexpr int u = decltype(uc)::value, k = k0 + u;
-        if constexpr (k < K) {
-          float f[16];
-          unpack16(l[u], f);
-          if (k < hk) {
-            unpack16_add(h[u], 256.0f, f);
-            if (k < h2k) {
-              const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
-              unpack16_add(ld_off<uint4>(ph2, vo), 65536.0f, f);
-            }
-          }
-          if constexpr (k < KR) {
-            gramr_v16& g = gramr_reg<k>(gr);
+      }
+      if constexpr (k < KR) {
+        gramr_v16& g = gramr_reg<k>(gr);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) g[e] = fmaf(nd, f[e], g[e]);
-            // (pins the group's FMAs HERE: left alone, the optimizer sinks the FMAs of all groups
-            // behind the last `k < hk` join and keeps 16 decoded floats per group alive until then)
-            asm volatile("" : "+v"(g));
-          } else {
-            float4* const gp = gl4 + (k - KR) * 4 * NT + tid;
+        for (int e = 0; e < 16; ++e) g[e] = fmaf(nd, f[e], g[e]);
+        // (pins the group's FMAs HERE: left alone, the optimizer sinks the FMAs of all groups
+        // behind the last `k < hk` join and keeps 16 decoded floats per group alive until then)
+        asm volatile("" : "+v"(g));
+      } else {
+        float4* const gp = gl4 + (k - KR) * 4 * NT + tid;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float4 v = gp[j * NT];
-              v.x = fmaf(nd, f[4 * j + 0], v.x);
-              v.y = fmaf(nd, f[4 * j + 1], v.y);
-              v.z = fmaf(nd, f[4 * j + 2], v.z);
-              v.w = fmaf(nd, f[4 * j + 3], v.w);
-              gp[j * NT] = v;
-            }
-          }
+        for (int j = 0; j < 4; ++j) {
+          float4 v = gp[j * NT];
+          v.x = fmaf(nd, f[4 * j + 0], v.x);
+          v.y = fmaf(nd, f[4 * j + 1], v.y);
+          v.z = fmaf(nd, f[4 * j + 2], v.z);
+          v.w = fmaf(nd, f[4 * j + 3], v.w);
+          gp[j * NT] = v;
         }
+      }
+    };
+    if constexpr (DMA) {
+      // group k's lo lands in slot 2k % S, its hi (k < hk) in slot (2k + 1) % S of this wavefront's
+      // ring; lane L's 16 bytes at L * 16 of the slot -- every thread reads back what it asked for
+      auto request = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
+        __builtin_amdgcn_global_load_lds(plo + vo, ring_w + ((2 * k) % kGramrSlots) * 1024, 16, 0, 0);
+        if (k < hk)
+          __builtin_amdgcn_global_load_lds(phi + vo, ring_w + ((2 * k + 1) % kGramrSlots) * 1024, 16, 0, 0);
+      };
+      static_for<(kGramrAhead < K ? kGramrAhead : K)>([&](auto kc) __attribute__((always_inline)) { request(kc); });
+      static_for<K>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k + kGramrAhead < K) request(std::integral_constant<int, k + kGramrAhead>{});
+        // requests younger than group k's: one per group ahead, two where the group has a hi plane
+        // (loads complete in order: once at most that many are outstanding, group k has landed)
+        constexpr int ahead = (K - 1 - k) < kGramrAhead ? (K - 1 - k) : kGramrAhead;
+        int with_hi = hk - k - 1;
+        with_hi = with_hi < 0 ? 0 : (with_hi > ahead ? ahead : with_hi);
+        switch (with_hi) {
+          case 0: SLIM_VMCNT(ahead); break;
+          case 1: SLIM_VMCNT(ahead + 1); break;
+          default: SLIM_VMCNT(ahead + 2); break;
+        }
+        static_assert(kGramrAhead <= 2, "one case per group ahead");
+        asm volatile("" ::: "memory");
+        const uint4 lo = *reinterpret_cast<const uint4*>(ring_w + ((2 * k) % kGramrSlots) * 1024 + lane * 16);
+        uint4 hi = make_uint4(0u, 0u, 0u, 0u);
+        if (k < hk) hi = *reinterpret_cast<const uint4*>(ring_w + ((2 * k + 1) % kGramrSlots) * 1024 + lane * 16);
+        consume(kc, lo, hi);
         __builtin_amdgcn_sched_barrier(0);
       });
-    });
+    } else {
+      constexpr int GRP = 4;
+      static_for<(K + GRP - 1) / GRP>([&](auto k0c) __attribute__((always_inline)) {
+        constexpr int k0 = decltype(k0c)::value * GRP;
+        uint4 l[GRP], h[GRP];
+        static_for<GRP>([&](auto uc) __attribute__((always_inline)) {
+          constexpr int u = decltype(uc)::value, k = k0 + u;
+          if constexpr (k < K) {
+            const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
+            l[u] = ld_off<uint4>(plo, vo);
+            if (k < hk) h[u] = ld_off<uint4>(phi, vo);
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);  // (the loads of ONE group of GRP chunks in flight, not of all)
+        static_for<GRP>([&](auto uc) __attribute__((always_inline)) {
+          constexpr int u = decltype(uc)::value, k = k0 + u;
+          if constexpr (k < K) consume(std::integral_constant<int, k>{}, l[u], h[u]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    }
   };
+#undef SLIM_VMCNT
   int nrows_read = 0, ngroups_read = 0;  // rows applied (fold + updates), hi / hi2 groups among them
   // float index in g_lds of rank r >= R0
   auto lds_index = [&](const int r) __attribute__((always_inline)) -> int {

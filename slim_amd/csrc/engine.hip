@@ -1096,15 +1096,17 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     GramrFn fn_r = nullptr;
     int gramr_kr = 0, gramr_kl = 0;
     if (use_gram && m->G_ready && !m->Gp_tried) (void)pack_gram(m);
+    size_t gramr_lds = 0;
+    bool gramr_dma = true;  // rows through the LDS ring (SLIM_GPU_GRAMR_DMA=0: register loads)
+    if (const char* e = std::getenv("SLIM_GPU_GRAMR_DMA")) gramr_dma = std::atoi(e) != 0;
     if (use_gram && m->Gp_ready && !std::getenv("SLIM_GPU_NO_GRAMR"))
-      fn_r = gramr_kernel(m->Gp_nchunks, &gramr_kr, &gramr_kl);
+      fn_r = gramr_kernel(m->Gp_nchunks, gramr_dma, &gramr_kr, &gramr_kl, &gramr_lds);
     const bool use_gramr = fn_r != nullptr;
     if (use_gramr) {
       gram_nw = kGramrNT / 64;
       gram_v = 1;  // (x only in the slab: g is on chip)
     }
-    const size_t gram_lds = use_gramr ? sizeof(float) * (size_t)gramr_kl * kPackGroup
-                                      : (gram_v > 0 ? sizeof(float) * (size_t)ncols_pad : 0);
+    const size_t gram_lds = use_gramr ? gramr_lds : (gram_v > 0 ? sizeof(float) * (size_t)ncols_pad : 0);
     // tile width: 32 item columns per workgroup (128-byte residual lines) unless the row
     // offsets would overflow the kernel's 32-bit byte offsets
     int tileP = kernel == SLIMGPU_KERNEL_TILE16 ? 16 : 32;

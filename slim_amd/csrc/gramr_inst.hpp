@@ -10,8 +10,10 @@ using GramrFn = void (*)(const DevMatrix, const SolveArgs, const GramPacked);
 
 // the smallest instantiation whose K = KR + KL groups of 8192 ranks cover nchunks 16-rank chunks
 // (nullptr: more items than the largest one holds on chip -- 106 496)
-GramrFn gramr_kernel(int nchunks, int* kr, int* kl);
-GramrFn gramr_kernel_k13();  // <10, 3>: its own translation unit (compiles beside the others)
+// dma: the variant that streams rows through an LDS ring (global_load_lds); lds_bytes = the dynamic
+// LDS the chosen instantiation needs
+GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes);
+GramrFn gramr_kernel_k13(bool dma);  // <10, 3>: its own translation unit (compiles beside the others)
 
 using PackScanFn = void (*)(const float*, int64_t, int, const int32_t*, int32_t*, int32_t*, int32_t*);
 using PackWriteFn = void (*)(const float*, int64_t, int, const int32_t*, int, uint8_t*, int64_t, uint8_t*,

@@ -2,5 +2,5 @@
 #include "cd_gramr.hpp"
 #include "gramr_inst.hpp"
 namespace slimamd {
-GramrFn gramr_kernel_k13() { return cd_gramr_kernel<10, 3>; }
+GramrFn gramr_kernel_k13(bool dma) { return dma ? cd_gramr_kernel<10, 3, true> : cd_gramr_kernel<10, 3, false>; }
 }  // namespace slimamd
