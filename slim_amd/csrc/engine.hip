@@ -1097,7 +1097,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     int gramr_kr = 0, gramr_kl = 0;
     if (use_gram && m->G_ready && !m->Gp_tried) (void)pack_gram(m);
     size_t gramr_lds = 0;
-    bool gramr_dma = true;  // rows through the LDS ring (SLIM_GPU_GRAMR_DMA=0: register loads)
+    // rows through the LDS ring (global_load_lds) where a row is many groups long -- measured
+    // (profiles/r05/gramr_dma_ab.txt): C4, 13 groups, kernel 6.62 -> 5.37 s; C5, 3 groups, where
+    // one round of register loads already holds the whole row, 1.32 -> 1.41 s.
+    // SLIM_GPU_GRAMR_DMA=0 / 1 forces either.
+    bool gramr_dma = (m->Gp_nchunks + kGramrNT - 1) / kGramrNT > 6;
     if (const char* e = std::getenv("SLIM_GPU_GRAMR_DMA")) gramr_dma = std::atoi(e) != 0;
     if (use_gram && m->Gp_ready && !std::getenv("SLIM_GPU_NO_GRAMR"))
       fn_r = gramr_kernel(m->Gp_nchunks, gramr_dma, &gramr_kr, &gramr_kl, &gramr_lds);
