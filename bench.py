@@ -541,14 +541,13 @@ def item_space_grid(args, dev, npairs=3):
                 "warm_pair_s": round(sum(warm) / len(warm), 2) if warm else None,
                 "roofline": {"bound": "hbm", "achieved": model_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": model_gbps / HBM_PEAK_GBS, "traffic": None,
-                             "note": "the last pair's launch of cd_gram_kernel: rows_of_G_read x 4 x ncols "
-                                     "bytes over its HIP-event time; PMC passes of the same launches: "
-                                     "profiles/r04/gram_c5_pmc_summary.txt (7.3 TB/s between L2 and the "
-                                     "fabric, Infinity-Cache hits included)"},
-                "byte_model": "rows_of_G_read x 4 x ncols bytes per solve (one row of G per update and "
-                              "per folded warm-start coefficient; g stays in LDS): row_GBps = that over "
-                              "the kernel time -- above the 8 TB/s of HBM means rows shared by the "
-                              "problems of a tile were served by L2 / Infinity Cache",
+                             "note": "the last pair's launch of the item-space kernel: the bytes of G its "
+                                     "updates and warm-start folds streamed (counted on the device: byte "
+                                     "planes, SLIMGPU_LastStats.gram_bytes) over its HIP-event time"},
+                "byte_model": "bytes of the rows of G read (one per update and per folded warm-start "
+                              "coefficient; packed rows: ncols bytes + 8192 per group of ranks that needs "
+                              "a second / third byte plane; g stays on chip): row_GBps = that over the "
+                              "kernel time",
                 "note": "round 3, tile kernel (profiles/r03/c5_grid_45pairs.txt): cold pair 157.9 s, "
                         "one-sweep pairs 38-40 s; the whole 45-pair grid: profiles/r04/"}
     finally:

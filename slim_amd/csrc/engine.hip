@@ -853,8 +853,8 @@ namespace {
 // leaves the handle on the float kernels, when G holds anything but integers in [0, 2^24)
 // (fractional or negative ratings) or the planes do not fit the free memory.
 bool pack_gram(slimgpu_matrix* m) {
+  if (std::getenv("SLIM_GPU_NO_GRAMR")) return false;  // (not an attempt: a later call may pack)
   m->Gp_tried = true;
-  if (std::getenv("SLIM_GPU_NO_GRAMR")) return false;
   const int32_t ncols = m->ncols;
   hipStream_t st = m->stream;
   const double t0 = now_ms();

@@ -532,6 +532,79 @@ def test_gram_kernel_geometries_match_tile_kernel(shape, binary):
     m.close()
 
 
+def _item_space_modes(monkeypatch, m, **kw):
+    """One solve per form of the item-space path: float G (cd_gram.hpp), byte planes with register
+    loads, byte planes through the LDS ring (cd_gramr.hpp)."""
+    out = []
+    for env in (dict(SLIM_GPU_NO_GRAMR="1"), dict(SLIM_GPU_GRAMR_DMA="0"), dict(SLIM_GPU_GRAMR_DMA="1")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        W, st = m.learn(kernel=KERNEL_GRAM, **kw)
+        out.append((W, st, m.column_stats()))
+        for k in env:
+            monkeypatch.delenv(k)
+    return out
+
+
+@pytest.mark.parametrize("shape,binary", [((40000, 3000, 0.004), False), ((30000, 15000, 0.002), False),
+                                          ((20000, 30000, 0.002), True), ((20000, 45000, 0.002), True)])
+def test_packed_gram_kernels_equal_the_float_kernel_bit_for_bit(monkeypatch, shape, binary):
+    """G as byte planes in popularity order (gram_pack.hpp) decodes to the very floats the unpacked
+    G holds and cd_gramr.hpp applies a row with the float kernel's fmaf sequence: the models are
+    EQUAL (not close), cold and warm-started, for 1 / 3 / 6 groups of 8192 ranks, with the row
+    streamed by register loads or through the LDS ring; its byte model counts fewer bytes."""
+    R = _random_ratings(shape[0], shape[1], shape[2], 5)
+    if binary:
+        R.data[:] = 1.0
+    m = DeviceMatrix.from_scipy(R, binary=binary)
+    cold = _item_space_modes(monkeypatch, m, seed=2)
+    first, _ = m.learn(seed=2, kernel=KERNEL_TILE, cluster=1, l1r=3.0, l2r=1.0)
+    warm = _item_space_modes(monkeypatch, m, seed=2, l1r=1.0, l2r=0.5, imodel=first)
+    for runs in (cold, warm):
+        (Wf, sf, cf), (Wp, sp_, cp), (Wd, sd, cd) = runs
+        assert Wf.nnz > 10000
+        assert maxdiff(Wf, Wp) == 0.0 and maxdiff(Wf, Wd) == 0.0
+        assert np.array_equal(cf.sweeps, cp.sweeps) and np.array_equal(cf.sweeps, cd.sweeps)
+        assert np.array_equal(cf.D, cp.D) and np.array_equal(cf.U, cd.U)
+        assert sf["objval"] == pytest.approx(sp_["objval"], rel=1e-6)
+        assert sf["gram_rows"] == sp_["gram_rows"] == sd["gram_rows"]
+        ncols_pad = (shape[1] + 63) // 64 * 64
+        assert sf["gram_bytes"] == sf["gram_rows"] * 4.0 * ncols_pad
+        assert 0 < sp_["gram_bytes"] == sd["gram_bytes"] <= 0.76 * sf["gram_bytes"]
+    m.close()
+
+
+def test_packed_gram_third_plane_and_the_float_fallback(monkeypatch):
+    """Co-rating counts beyond 65 535 take the third byte plane (70 000 users rate items 0-2: G
+    entries of 70 000), still bit-equal to the float kernel and within tolerance of the oracle's tile
+    walk; a matrix with fractional ratings cannot be packed (G is not integer-valued) and stays on
+    the float kernel."""
+    rng = np.random.default_rng(3)
+    nu, ni = 70000, 40
+    R = sp.random(nu, ni, density=0.2, format="lil", random_state=rng, dtype=np.float32)
+    R[:, :3] = 1.0
+    R = sp.csr_matrix(R)
+    R.data[:] = 1.0
+    R.sort_indices()
+    m = DeviceMatrix.from_scipy(R, binary=True)
+    (Wf, sf, cf), (Wp, sp_, cp), (Wd, sd, cd) = _item_space_modes(monkeypatch, m, seed=4, l1r=5.0, l2r=2.0)
+    assert Wf.nnz > 0 and maxdiff(Wf, Wp) == 0.0 and maxdiff(Wf, Wd) == 0.0
+    assert sp_["gram_bytes"] < sf["gram_bytes"]            # packed: (40 + hi + hi2 groups) < 4 * 64 per row
+    Wo, so, _, _ = O.learn_cd_tile(R, tileP=32, seed=4, nthreads=8, l1r=5.0, l2r=2.0, binary=True,
+                                   return_stats=True)
+    assert maxdiff(Wp, Wo) <= 5e-5 and np.array_equal(cp.nacols, so["nacols"])
+    assert (cp.sweeps == so["sweeps"]).mean() >= 0.98
+    m.close()
+    Rf = _random_ratings(40000, 3000, 0.004, 5)
+    Rf.data *= 0.5                                         # ratings 0.5 ... 2.5
+    m = DeviceMatrix.from_scipy(Rf)
+    Wg, sg = m.learn(seed=2, kernel=KERNEL_GRAM, l1r=0.25, l2r=0.25)
+    assert sg["kernel"] == KERNEL_GRAM and sg["gram_bytes"] == sg["gram_rows"] * 4.0 * 3008
+    Wt, _ = m.learn(seed=2, kernel=KERNEL_TILE, cluster=1, l1r=0.25, l2r=0.25)
+    assert maxdiff(Wg, Wt) <= 5e-5
+    m.close()
+
+
 def test_gram_kernel_warm_start_matches_oracle_tile_walk():
     """Warm start in item space (g -= x_j G[j, :] for the previous coefficients of the coordinates
     active now) against oracle_learn_cd_tile(..., imodel) (estimate.c:453-464, cd.c:108-110)."""
