@@ -332,6 +332,104 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         }
       }
       __syncthreads();
+      if (S.gram_bits == 2) {
+        // Lanes = COLUMNS (round 5).  The form below gives a wavefront one column at a time and
+        // counts with P ballots per 64 nnz: ~2 wavefront instructions per nnz, and a slice is only
+        // ~300 nnz long.  Here a wavefront takes 64 columns that are neighbours in the cost-ordered
+        // work list (slices of about the same length), every lane walks ITS column's slice and adds
+        // the users' words into a bit-sliced counter -- plane p holds bit p of the P running counts,
+        // eight words enter through a carry-save tree (Harley-Seal), the carries ripple upward only
+        // while some lane still has one -- ~6 lane operations per nnz, i.e. ~0.1 wavefront
+        // instructions per nnz, and no cross-lane reduction at all: at the end every lane turns its
+        // planes into the P counts of its column and writes one 128-byte line.  Positions at or
+        // behind the tile's own only (symmetric fill).
+        constexpr int NPL = 16;  // planes: counts below 2^16 per (column slice, item) -- a member's
+                                 // user range holds at most 37 888 users (148 KB of LDS)
+        const int32_t* __restrict__ ord = S.order;
+        for (int p0 = base + wave * 64; p0 < S.nwork; p0 += NW * 64) {
+          const int pl = p0 + lane;
+          const bool have = pl < S.nwork;
+          const int i = have ? ord[pl] : 0;
+          int64_t cs = 0, ce = 0;
+          if (have) {
+            cs = csplit[(int64_t)i * (K + 1) + mk];
+            ce = csplit[(int64_t)i * (K + 1) + mk + 1];
+          }
+          const int len = (int)(ce - cs);
+          uint32_t ones = 0u, twos = 0u, fours = 0u, hi[NPL - 3];
+#pragma unroll
+          for (int pp = 0; pp < NPL - 3; ++pp) hi[pp] = 0u;
+          int nhi = 0;  // planes of hi[] that may be non-zero in some lane (uniform)
+#define SLIM_CSA(h, l, a, b, c)      \
+  {                                  \
+    const uint32_t u_ = (a) ^ (b);   \
+    h = ((a) & (b)) | (u_ & (c));    \
+    l = u_ ^ (c);                    \
+  }
+          // a step = 32 ids of every lane's slice, i.e. one whole 128-byte line per lane (eight
+          // 16-byte loads, dword-aligned): a lane that took 8 ids per step came back to its line
+          // four times, and with 1024 lanes per CU walking different lines the caches did not
+          // keep them -- the HBM traffic was several times the column view
+          struct __attribute__((packed, aligned(4))) ids4 { int32_t a, b, c, d; };
+          const int64_t last4 = S.nnz_last >= 3 ? S.nnz_last - 3 : 0;
+          for (int t = 0; __ballot(t < len) != 0ull; t += 32) {
+            ids4 q4[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int64_t at = cs + t + 4 * j;
+              q4[j] = *reinterpret_cast<const ids4*>(ci + (at < last4 ? at : last4));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int uu[8] = {q4[2 * r].a, q4[2 * r].b, q4[2 * r].c, q4[2 * r].d,
+                                 q4[2 * r + 1].a, q4[2 * r + 1].b, q4[2 * r + 1].c, q4[2 * r + 1].d};
+              uint32_t w[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const bool ok = t + 8 * r + j < len && cs + t + 8 * r + j <= S.nnz_last;
+                w[j] = s_bits[ok ? uu[j] - ubase : 0];
+                w[j] = ok ? w[j] : 0u;
+              }
+              uint32_t ta, tb, fa, fb, e8;
+              SLIM_CSA(ta, ones, ones, w[0], w[1]);
+              SLIM_CSA(tb, ones, ones, w[2], w[3]);
+              SLIM_CSA(fa, twos, twos, ta, tb);
+              SLIM_CSA(ta, ones, ones, w[4], w[5]);
+              SLIM_CSA(tb, ones, ones, w[6], w[7]);
+              SLIM_CSA(fb, twos, twos, ta, tb);
+              SLIM_CSA(e8, fours, fours, fa, fb);
+              uint32_t carry = e8;  // into plane 3 and upward, while any lane carries
+#pragma unroll
+              for (int pp = 0; pp < NPL - 3; ++pp) {
+                if (__ballot(carry != 0u) == 0ull) break;
+                const uint32_t nc = hi[pp] & carry;
+                hi[pp] ^= carry;
+                carry = nc;
+                nhi = nhi > pp + 1 ? nhi : pp + 1;
+              }
+            }
+          }
+#undef SLIM_CSA
+          // planes -> the P counts of this lane's column
+          float cnt[P];
+#pragma unroll
+          for (int qq = 0; qq < P; ++qq)
+            cnt[qq] = (float)(((ones >> qq) & 1u) + (((twos >> qq) & 1u) << 1) + (((fours >> qq) & 1u) << 2));
+#pragma unroll
+          for (int pp = 0; pp < NPL - 3; ++pp) {
+            if (pp < nhi) {
+#pragma unroll
+              for (int qq = 0; qq < P; ++qq) cnt[qq] += (float)(((hi[pp] >> qq) & 1u) << (pp + 3));
+            }
+          }
+          if (have) {
+            float4* const out = reinterpret_cast<float4*>(part + (int64_t)i * P);
+#pragma unroll
+            for (int j = 0; j < P / 4; ++j)
+              out[j] = make_float4(cnt[4 * j], cnt[4 * j + 1], cnt[4 * j + 2], cnt[4 * j + 3]);
+          }
+        }
+      } else {
       // (slices are short here -- a column's nnz over 32 members -- so the slice bounds and the
       // position of the NEXT column are requested while this one is counted)
       int64_t cs_n = 0, ce_n = 0;
@@ -365,6 +463,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
 #pragma unroll
         for (int qq = 0; qq < P; ++qq) v = lane == qq ? (float)cnt[qq] : v;
         if (lane < P) part[(int64_t)i * P + lane] = v;  // one 128-byte line per column
+      }
       }
       cluster_barrier();  // every member's partial sums are published
     }

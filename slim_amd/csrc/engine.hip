@@ -1052,6 +1052,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       const double tb = now_ms();
       drop_screen_cache(m);  // (G holds the same sums for every column)
       float* dG = ws_get<float>(m->ws_G, (size_t)ncols * (size_t)G_ld);
+      const double t_alloc = now_ms();
       HIP_TRY(hipMemsetAsync(dG, 0, G_bytes, stream));
       m->G_ld = G_ld;
       LearnOptions bo = opt;
@@ -1069,14 +1070,17 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       slim_csr_t* none = learn_cd(m, bo, nullptr, &bst, nullptr, 0, false);
       if (!none) return fail(bst);
       csr_free(none);
+      const double t_sums = now_ms();
+      const double sums_kernel_ms = last_stats().kernel_ms;
       m->G_ready = true;
       m->Gp_ready = false;
       m->Gp_tried = false;
       if (!pack_gram(m)) m->Gp_ready = false;
       m->G_build_ms = now_ms() - tb;
       if (const char* te = std::getenv("SLIM_GPU_TRACE"); te && std::atoi(te) >= 1)
-        std::fprintf(stderr, "[trace] G = R^T R (%d x %d, %.2f GB) built in %.1f ms\n", ncols, ncols,
-                     G_bytes * 1e-9, m->G_build_ms);
+        std::fprintf(stderr, "[trace] G = R^T R (%d x %d, %.2f GB) built in %.1f ms: allocation %.1f, sums %.1f "
+                     "(kernel %.1f), byte planes %.1f\n", ncols, ncols, G_bytes * 1e-9, m->G_build_ms,
+                     t_alloc - tb, t_sums - t_alloc, sums_kernel_ms, now_ms() - t_sums);
     }
     if (kernel == SLIMGPU_KERNEL_AUTO)
       kernel = lds_need <= 64 * 1024 ? SLIMGPU_KERNEL_WAVE_LDS : SLIMGPU_KERNEL_TILE;
@@ -1529,7 +1533,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.G_ld = m->G_ld;
       S.tile_nunion = d_nunion;
       S.gram_pos = nullptr;
-      S.gram_bits = (gram_bits_lds && clusterK == 32 && tile_lds == gram_bits_lds) ? 1 : 0;
+      // (2: lanes = columns, bit-sliced counters; SLIM_GPU_GBITS=1: the round-4 form, one column
+      // per wavefront and 32 ballots per 64 nnz)
+      S.gram_bits = (gram_bits_lds && clusterK == 32 && tile_lds == gram_bits_lds) ? 2 : 0;
+      if (const char* e = std::getenv("SLIM_GPU_GBITS"); e && S.gram_bits) S.gram_bits = std::atoi(e) == 1 ? 1 : 2;
       if (opt.build_G) {
         if (attempt > 0 || cluster_fallback || npend != ncols) {
           // (the symmetric fill needs every column in ONE launch; a re-plan after a cluster
