@@ -423,6 +423,33 @@ def dry_run(args, mat, ncols, per_gpu, opts, nnz):
         ranks.append({"rank": r, "columns": int(st["ncols_solved"]), "kernel_ms": round(st["kernel_ms"], 1),
                       "wall_ms": round(1e3 * (time.perf_counter() - t0), 1),
                       "alg_bytes": st["alg_bytes"]})
+    # the same for the N >= 4 extra in item space (strong_whole_matrix.item_space): every rank builds
+    # G = R^T R for itself (measured once here) and solves shard r of ALL the columns
+    item = None
+    if not args.no_item_space:
+        saved = {k: os.environ.pop(k, None) for k in ("SLIM_GPU_NO_GRAM", "SLIM_GPU_NO_GRAMCD")}
+        try:
+            ir = []
+            for r in range(N):
+                t0 = time.perf_counter()
+                _, st = mat.learn(col_begin=0, col_end=ncols, shard=(r, N), **dict(opts, kernel=5))
+                ir.append({"rank": r, "columns": int(st["ncols_solved"]), "kernel_ms": round(st["kernel_ms"], 1),
+                           "G_build_ms": round(st["gram_build_ms"], 1),
+                           "wall_ms": round(1e3 * (time.perf_counter() - t0), 1)})
+            g_ms = max(x["G_build_ms"] for x in ir)
+            solve_ms = max(x["wall_ms"] - x["G_build_ms"] for x in ir)
+            free_b, total_b = __import__("torch").cuda.mem_get_info()
+            item = {"ranks": ir, "G_build_ms_per_rank": g_ms,
+                    "projected_step_s": round((g_ms + solve_ms) * 1e-3, 1),
+                    "hbm_in_use_gb_with_G": round((total_b - free_b) / 1e9, 1), "hbm_total_gb": round(total_b / 1e9, 1),
+                    "note": "whole matrix in item space at N ranks: each rank pays the G build (measured once, on "
+                            "rank 0's shard) plus its shard; memory = R + G (floats + byte planes) + slabs on one GPU"}
+        except Exception as e:   # noqa: BLE001
+            item = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            for k, v in saved.items():
+                if v is not None:
+                    os.environ[k] = v
     km = [x["kernel_ms"] for x in ranks]
     wm = [x["wall_ms"] for x in ranks]
     mean = sum(km) / len(km)
@@ -432,13 +459,15 @@ def dry_run(args, mat, ncols, per_gpu, opts, nnz):
     bcast_s = bytes_R / 50e9                   # ring broadcast over xGMI: one link's ~50 GB/s effective
     whole_s = step_s * (ncols / float(N)) / max(1, per_gpu) * 1.25
     warm_s = warmup * step_s / 32.0 * 2.0      # warm-up steps run 1/32 of a step's range
-    total = 60.0 + bcast_s + warm_s + steps * step_s + whole_s
+    item_s = item["projected_step_s"] if item and "projected_step_s" in item else 0.0
+    total = 60.0 + bcast_s + warm_s + steps * step_s + whole_s + item_s
     return {"dry_run_world": N, "columns_per_rank_and_step": per_gpu, "range": span,
-            "ranks": ranks, "kernel_ms_mean": round(mean, 1),
+            "ranks": ranks, "item_space_whole_matrix": item, "kernel_ms_mean": round(mean, 1),
             "kernel_ms_spread": round((max(km) - min(km)) / mean, 4),
             "projected_command_s": {"start_up_and_generate": 60.0, "broadcast_R": round(bcast_s, 2),
                                     "warmup": round(warm_s, 1), "timed_steps": round(steps * step_s, 1),
-                                    "whole_matrix_step": round(whole_s, 1), "total": round(total, 1),
+                                    "whole_matrix_step": round(whole_s, 1),
+                                    "whole_matrix_step_item_space": round(item_s, 1), "total": round(total, 1),
                                     "limit": 1800.0, "fits": bool(total < 1800.0),
                                     "whole_matrix_step_runs": bool(total < WALL_BUDGET_S)},
             "note": "one device, ranks solved one after the other: no RCCL, no peer copies -- what "

@@ -123,9 +123,12 @@ typedef enum {
                                   interleaved r[user][32] in HBM (large matrices) */
   SLIMGPU_KERNEL_TILE16 = 4,   /* same with 16 items per workgroup             */
   SLIMGPU_KERNEL_GRAM = 5      /* item-space CD: one workgroup per item, g = a_i.r over the
-                                  ITEMS in LDS, updates read rows of G = R^T R (built on the
-                                  first such solve, kept with the handle; <= ~40K items).
-                                  AUTO takes it for repeated solves of one matrix         */
+                                  ITEMS kept on chip, an update reads one row of G = R^T R
+                                  (built on the first such solve and kept with the handle: floats,
+                                  and byte planes of ~1-2 bytes per entry when G is integer-valued).
+                                  AUTO takes it when its byte model beats the residual kernel's
+                                  (ncols^2 / nnz < 45) and the call's columns -- times the solves
+                                  announced -- pay for G; no FSLIM form                         */
 } slimgpu_kernel_et;
 
 /* A training matrix staged in HBM: CSR as given + the column view (CSC, rows
@@ -158,7 +161,8 @@ int32_t SLIMGPU_MatrixGetColumnView(const slimgpu_matrix_t *mat, int64_t *colptr
 
 /* Announce that the matrix is about to be solved nsolves times (a model-selection grid,
  * src/programs/slim_mselect.c:94-113): with nsolves >= 2 SLIMGPU_KERNEL_AUTO may build
- * G = R^T R once and run every solve in item space (SLIMGPU_KERNEL_GRAM).  0 withdraws it. */
+ * G = R^T R for a grid whose single solves would not pay for it (SLIMGPU_KERNEL_GRAM: the
+ * automatic choice multiplies the columns of a call by nsolves).  0 withdraws it. */
 void SLIMGPU_MatrixExpectSolves(slimgpu_matrix_t *mat, int32_t nsolves);
 
 /* Scheduling cost proxy per item column (the Gram work G = sum over the column's
@@ -229,7 +233,9 @@ typedef struct slimgpu_stats_t {
                               this call (0 when it was there already)          */
   int64_t gram_rows;       /* SLIMGPU_KERNEL_GRAM: rows of G read (one per update and per
                               folded warm-start coefficient)                   */
-  double gram_bytes;       /* = gram_rows x 4 ncols: that kernel's byte model (it does
+  double gram_bytes;       /* bytes of G those rows streamed -- gram_rows x 4 ncols for the
+                              float kernels, the packed rows' bytes (counted on the device)
+                              for the byte-plane kernel: the item-space byte model (it does
                               not move what SURVEY.md 8(d)'s alg_bytes prices)  */
 } slimgpu_stats_t;
 int32_t SLIMGPU_LastStats(slimgpu_stats_t *out);

@@ -31,10 +31,15 @@ done
 cd $R
 [ -n "${SKIP_PMC:-}" ] || python scripts/pmc_to_json.py $O/${TAG}_pmc_FETCH_SIZE/run_counter_collection.csv $O/${TAG}_pmc_WRITE_SIZE/run_counter_collection.csv \
   $O/cal_FETCH_SIZE/cal_counter_collection.csv $O/cal_WRITE_SIZE/cal_counter_collection.csv $O/${TAG}_pmc_FETCH_SIZE.json > $O/${TAG}_pmc_entry.json
+# the item_space_step launch of the same passes (default workload only): its own entry
+if [ -z "${SKIP_PMC:-}" ] && grep -q '"item_space_step": {"columns"' $O/${TAG}_pmc_FETCH_SIZE.json 2>/dev/null; then
+  PMC_ITEM_SPACE=1 python scripts/pmc_to_json.py $O/${TAG}_pmc_FETCH_SIZE/run_counter_collection.csv $O/${TAG}_pmc_WRITE_SIZE/run_counter_collection.csv \
+    $O/cal_FETCH_SIZE/cal_counter_collection.csv $O/cal_WRITE_SIZE/cal_counter_collection.csv $O/${TAG}_pmc_FETCH_SIZE.json > $O/${TAG}_pmc_entry_item_space.json
+fi
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 grep trace $O/${TAG}_bench.err 2>/dev/null | cut -c1-400
 cat $O/${TAG}_bench.json 2>/dev/null | tail -1 | cut -c1-1500
-grep -E "cd_tile|cd_wave|Name" $O/${TAG}_stats/run_kernel_stats.csv 2>/dev/null | head -5
+grep -E "cd_tile|cd_wave|cd_gram|Name" $O/${TAG}_stats/run_kernel_stats.csv 2>/dev/null | head -8
 cat $O/${TAG}_pmc_entry.json
 # keep the merge-back small: the per-dispatch traces are large
 find $O -name "*kernel_trace.csv" -size +20M -delete

@@ -20,14 +20,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def counter(path, kernel_substr, name):
-    tot, launches, secs = 0.0, 0, []
-    for row in csv.DictReader(open(path)):
-        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == name:
-            tot += float(row["Counter_Value"])
-            launches += 1
-            secs.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9)
-    return tot, launches, secs
+def counter(path, kernel_substr, name, take=None):
+    """Sum of a counter over the dispatches of a kernel (take: only the first `take` of them in
+    time order -- the bench command's extras launch the tile kernel again to build G)."""
+    rows = [r for r in csv.DictReader(open(path))
+            if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == name]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    if take is not None:
+        rows = rows[:take]
+    tot = sum(float(r["Counter_Value"]) for r in rows)
+    secs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9 for r in rows]
+    return tot, len(rows), secs
 
 
 def main():
@@ -37,13 +40,15 @@ def main():
     sw, _, _ = counter(cal_w, "scatter<128", "WRITE_SIZE")
     sf, _, _ = counter(cal_f, "scatter<128", "FETCH_SIZE")
     fcorr, wcorr = known / (gf * 1024), known / (sw * 1024)
-    f, nf, tf = counter(fetch_csv, "cd_tile_kernel", "FETCH_SIZE")
-    w, nw, tw = counter(write_csv, "cd_tile_kernel", "WRITE_SIZE")
     bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
     cfg = bench["config"]
     kname = "cd_tile_kernel" if cfg["kernel"].startswith("tile") else "cd_wave_kernel"
-    f, nf, tf = counter(fetch_csv, kname, "FETCH_SIZE")
-    w, nw, tw = counter(write_csv, kname, "WRITE_SIZE")
+    item_space = os.environ.get("PMC_ITEM_SPACE")   # entry for the item_space_step launch of the same run
+    take = int(bench.get("steps", 1))
+    if item_space:
+        kname, take = "cd_gramr_kernel<10", 1
+    f, nf, tf = counter(fetch_csv, kname, "FETCH_SIZE", take)
+    w, nw, tw = counter(write_csv, kname, "WRITE_SIZE", take)
     entry = {
         "match": {"workload": cfg["workload"].split(" ")[0], "scale": cfg["scale"],
                   "seed": cfg.get("seed", 1),
@@ -60,6 +65,14 @@ def main():
         "kernel_seconds_under_pmc": [round(x, 2) for x in tf + tw],
         "alg_bytes_per_launch_same_run": bench["roofline"]["alg_bytes_per_launch"],
     }
+    if item_space:
+        # a streaming kernel: FETCH_SIZE tallies its 128-byte requests at 64 bytes like the
+        # calibration gathers (MI355X_MICROARCH.md, HBM section); same corrections
+        sys.path.insert(0, ROOT)
+        import bench as B
+        entry["match"]["kernel"] = "item_space_step"
+        entry["kernel_hash"] = B.kernel_hash("gram")
+        entry["alg_bytes_per_launch_same_run"] = bench["item_space_step"]["roofline"]["alg_bytes_per_launch"]
     entry["traffic_over_algorithmic"] = entry["traffic_bytes_per_launch"] / max(
         entry["alg_bytes_per_launch_same_run"], 1.0)
     secs = entry["kernel_seconds_under_pmc"]

@@ -93,8 +93,8 @@ constexpr int kGramrAhead = 2;                       // groups requested ahead o
 constexpr int kGramrSlots = 2 * (kGramrAhead + 1);   // 1 KB slots per wavefront: lo + hi per group
 constexpr int kGramrRingBytes = (kGramrNT / 64) * kGramrSlots * 1024;
 
-template <int KR, int KL, bool DMA = false>
-__global__ __launch_bounds__(kGramrNT, (KR <= 2 && KL == 0) ? 4 : 2) void cd_gramr_kernel(
+template <int KR, int KL, bool DMA = false, int WPS = ((KR <= 2 && KL == 0) ? 4 : 2)>
+__global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     const DevMatrix A, const SolveArgs S, const GramPacked P) {
   constexpr int NT = kGramrNT, K = KR + KL;
   constexpr int KRA = KR > 0 ? KR : 1;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kGramrNT, (KR <= 2 && KL == 0) ? 4 : 2) void cd_gra
     }
   };
 #undef SLIM_VMCNT
-  int nrows_read = 0, ngroups_read = 0;  // rows applied (fold + updates), hi / hi2 groups among them
+  int nrows_read = 0, nhi16_read = 0;  // rows applied (fold + updates); 16-byte chunks of hi / hi2 planes among them
   // float index in g_lds of rank r >= R0
   auto lds_index = [&](const int r) __attribute__((always_inline)) -> int {
     const int rr = r - R0;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kGramrNT, (KR <= 2 && KL == 0) ? 4 : 2) void cd_gra
     int niters = 0, conv = 0;
     uint32_t Dq = 0, Uq = 0;  // SURVEY.md 8(d) counters, per lane and sweep (same in every wave)
     nrows_read = 0;
-    ngroups_read = 0;
+    nhi16_read = 0;
 
     // ONE loop carries the whole problem, so that the registers holding g see one site that
     // updates them (apply) and one that reads them out (fetch_g) -- with a site per phase the
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kGramrNT, (KR <= 2 && KL == 0) ? 4 : 2) void cd_gra
           init_row = false;
         } else {
           ++nrows_read;
-          ngroups_read += hk + h2k;
+          nhi16_read += min(hk * (kPackGroup / 16), nchunks) + min(h2k * (kPackGroup / 16), nchunks);
         }
         gi = fmaf(nd, gsel, gi);
       }
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kGramrNT, (KR <= 2 && KL == 0) ? 4 : 2) void cd_gra
         S.st_D[item] = (int64_t)s_D;
         S.st_U[item] = (int64_t)s_U;
         S.st_G[item] = nrows_read;  // (the engine reports the staging pass's G for the column)
-        S.st_B[item] = (int64_t)nrows_read * P.ldb + (int64_t)ngroups_read * kPackGroup;
+        S.st_B[item] = (int64_t)nrows_read * P.ldb + (int64_t)nhi16_read * 16;
         S.st_err[item] = err;
         S.st_obj[item] = err + (float)reg;
       }

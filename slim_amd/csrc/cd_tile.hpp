@@ -371,13 +371,14 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           // four times, and with 1024 lanes per CU walking different lines the caches did not
           // keep them -- the HBM traffic was several times the column view
           struct __attribute__((packed, aligned(4))) ids4 { int32_t a, b, c, d; };
-          const int64_t last4 = S.nnz_last >= 3 ? S.nnz_last - 3 : 0;
           for (int t = 0; __ballot(t < len) != 0ull; t += 32) {
             ids4 q4[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const int64_t at = cs + t + 4 * j;
-              q4[j] = *reinterpret_cast<const ids4*>(ci + (at < last4 ? at : last4));
+              // (a lane whose slice has ended keeps reading behind it, at most 31 entries beyond the
+              // column view, which is allocated with that slack; what it reads is dropped below)
+              const int64_t at = t < len ? cs + t + 4 * j : cs;
+              q4[j] = *reinterpret_cast<const ids4*>(ci + at);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -386,7 +387,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
               uint32_t w[8];
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
-                const bool ok = t + 8 * r + j < len && cs + t + 8 * r + j <= S.nnz_last;
+                const bool ok = t + 8 * r + j < len;
                 w[j] = s_bits[ok ? uu[j] - ubase : 0];
                 w[j] = ok ? w[j] : 0u;
               }

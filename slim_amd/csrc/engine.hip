@@ -328,7 +328,8 @@ void build_column_view(slimgpu_matrix* m) {
   hipStream_t st = m->stream;
   const int64_t nnz = m->nnz;
   m->d_colptr = dev_alloc<int64_t>((size_t)m->ncols + 1);
-  m->d_colind = dev_alloc<int32_t>((size_t)nnz);
+  // (+ 64 entries of slack: the G builder reads whole 128-byte lines of a column slice, cd_tile.hpp)
+  m->d_colind = dev_alloc<int32_t>((size_t)nnz + 64);
   m->d_colval = m->binary ? nullptr : dev_alloc<float>((size_t)nnz);
   m->d_cnorm = dev_alloc<float>((size_t)m->ncols);
   m->d_csq = dev_alloc<float>((size_t)m->ncols);
@@ -711,7 +712,7 @@ slimgpu_matrix_t* matrix_clone_to_device(const slimgpu_matrix_t* src, int32_t de
     m->d_rowind = dev_alloc<int32_t>(nz);
     m->d_rowval = m->binary ? nullptr : dev_alloc<float>(nz);
     m->d_colptr = dev_alloc<int64_t>((size_t)m->ncols + 1);
-    m->d_colind = dev_alloc<int32_t>(nz);
+    m->d_colind = dev_alloc<int32_t>(nz + 64);
     m->d_colval = m->binary ? nullptr : dev_alloc<float>(nz);
     m->d_cnorm = dev_alloc<float>((size_t)m->ncols);
     m->d_csq = dev_alloc<float>((size_t)m->ncols);

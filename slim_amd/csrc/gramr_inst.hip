@@ -1,5 +1,6 @@
 // cd_gramr_kernel<KR, KL> for up to 49 152 items, and the packing kernels; see gramr_inst.hpp
 #define SLIM_GRAM_PACK_KERNELS
+#include <cstdlib>
 #include "cd_gramr.hpp"
 #include "gramr_inst.hpp"
 namespace slimamd {
@@ -8,7 +9,15 @@ GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes)
   *kl = 0;
   GramrFn fn = nullptr;
   if (k <= 1) { *kr = 1; fn = dma ? cd_gramr_kernel<1, 0, true> : cd_gramr_kernel<1, 0, false>; }
-  else if (k <= 3) { *kr = 3; fn = dma ? cd_gramr_kernel<3, 0, true> : cd_gramr_kernel<3, 0, false>; }
+  else if (k <= 3) {
+    *kr = 3;
+    // 128 VGPRs, two workgroups per CU (a few spills outside the row loop): a one-sweep C5 pair
+    // 1.32 -> 1.19 s, the cold pair 3.30 -> 3.43 s -- 40 of the grid's 45 pairs are one-sweep
+    // pairs.  SLIM_GPU_GRAMR_WPS=2: 256 VGPRs, one workgroup per CU.
+    const char* e = std::getenv("SLIM_GPU_GRAMR_WPS");
+    if (e && std::atoi(e) == 2) fn = dma ? cd_gramr_kernel<3, 0, true> : cd_gramr_kernel<3, 0, false>;
+    else fn = dma ? cd_gramr_kernel<3, 0, true, 4> : cd_gramr_kernel<3, 0, false, 4>;
+  }
   else if (k <= 6) { *kr = 6; fn = dma ? cd_gramr_kernel<6, 0, true> : cd_gramr_kernel<6, 0, false>; }
   else if (k <= 13) { *kr = 10; *kl = 3; fn = gramr_kernel_k13(dma); }
   *lds_bytes = sizeof(float) * (size_t)*kl * kPackGroup + (dma ? (size_t)kGramrRingBytes : 0);

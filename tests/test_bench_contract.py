@@ -63,7 +63,7 @@ def test_dry_run_projection_adds_up():
             return None, {"ncols_solved": (col_end - col_begin) // shard[1], "kernel_ms": 50000.0 + 500.0 * r,
                           "alg_bytes": 3.6e14}
 
-    args = _default_args(dry_run_world=8)
+    args = _default_args(dry_run_world=8, no_item_space=True)
     out = bench.dry_run(args, Mat(), 100000, 8192, {}, 10 ** 9)
     assert calls[0] == (0, 2048, (0, 8))                       # the warm-up: 1/32 of the range
     assert [c[2] for c in calls[1:]] == [(r, 8) for r in range(8)] and calls[1][:2] == (0, 65536)
@@ -71,5 +71,5 @@ def test_dry_run_projection_adds_up():
     assert abs(out["kernel_ms_spread"] - 3500.0 / 51750.0) < 1e-3
     p = out["projected_command_s"]
     assert abs(p["total"] - (p["start_up_and_generate"] + p["broadcast_R"] + p["warmup"] + p["timed_steps"]
-                             + p["whole_matrix_step"])) < 0.2
+                             + p["whole_matrix_step"] + p["whole_matrix_step_item_space"])) < 0.2
     assert p["limit"] == 1800.0 and isinstance(p["fits"], bool)
