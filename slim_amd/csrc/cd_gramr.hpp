@@ -37,6 +37,10 @@
 #include "cd_tile.hpp"
 #include "gram_pack.hpp"
 
+#ifndef SLIM_GRAMR_AUX
+#define SLIM_GRAMR_AUX 0
+#endif
+
 namespace slimamd {
 
 // one group of this thread's g: 16 consecutive registers, so that entry e of a group can be read
@@ -89,14 +93,15 @@ __device__ __forceinline__ float gramr_sel(GramrRegs<KRA>& gr, const int k, cons
 // DMA: the row is streamed into a per-wavefront LDS ring by `global_load_lds_dwordx4` (LDS-DMA: no
 // VGPR holds data in flight) kGramrAhead groups ahead of the one being decoded, instead of GRP
 // register loads per round trip.
-constexpr int kGramrAhead = 2;                       // groups requested ahead of the one consumed
-constexpr int kGramrSlots = 2 * (kGramrAhead + 1);   // 1 KB slots per wavefront: lo + hi per group
-constexpr int kGramrRingBytes = (kGramrNT / 64) * kGramrSlots * 1024;
+// AH = groups requested ahead of the one consumed; the ring has 2 (AH + 1) slots of 1 KB per
+// wavefront (lo + hi per group in flight).
+constexpr int gramr_ring_bytes(int ah) { return (kGramrNT / 64) * 2 * (ah + 1) * 1024; }
 
-template <int KR, int KL, bool DMA = false, int WPS = ((KR <= 2 && KL == 0) ? 4 : 2)>
+template <int KR, int KL, bool DMA = false, int WPS = ((KR <= 2 && KL == 0) ? 4 : 2), int AH = 2>
 __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     const DevMatrix A, const SolveArgs S, const GramPacked P) {
   constexpr int NT = kGramrNT, K = KR + KL;
+  constexpr int kGramrAhead = AH, kGramrSlots = 2 * (AH + 1);
   constexpr int KRA = KR > 0 ? KR : 1;
   constexpr int R0 = KR * kPackGroup;  // first rank held in LDS
   static_assert(KR <= 12, "register select covers 12 groups");
@@ -174,9 +179,11 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       auto request = [&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
-        __builtin_amdgcn_global_load_lds(plo + vo, ring_w + ((2 * k) % kGramrSlots) * 1024, 16, 0, 0);
+        // (aux = SLIM_GRAMR_AUX: 2 = nt, a row is read once by one CU -- MI355X guide, "nt-weights")
+        __builtin_amdgcn_global_load_lds(plo + vo, ring_w + ((2 * k) % kGramrSlots) * 1024, 16, 0, SLIM_GRAMR_AUX);
         if (k < hk)
-          __builtin_amdgcn_global_load_lds(phi + vo, ring_w + ((2 * k + 1) % kGramrSlots) * 1024, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(phi + vo, ring_w + ((2 * k + 1) % kGramrSlots) * 1024, 16, 0,
+                                           SLIM_GRAMR_AUX);
       };
       static_for<(kGramrAhead < K ? kGramrAhead : K)>([&](auto kc) __attribute__((always_inline)) { request(kc); });
       static_for<K>([&](auto kc) __attribute__((always_inline)) {
@@ -187,12 +194,10 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         constexpr int ahead = (K - 1 - k) < kGramrAhead ? (K - 1 - k) : kGramrAhead;
         int with_hi = hk - k - 1;
         with_hi = with_hi < 0 ? 0 : (with_hi > ahead ? ahead : with_hi);
-        switch (with_hi) {
-          case 0: SLIM_VMCNT(ahead); break;
-          case 1: SLIM_VMCNT(ahead + 1); break;
-          default: SLIM_VMCNT(ahead + 2); break;
-        }
-        static_assert(kGramrAhead <= 2, "one case per group ahead");
+        static_for<ahead + 1>([&](auto wc) __attribute__((always_inline)) {
+          constexpr int wh = decltype(wc)::value;
+          if (with_hi == wh) SLIM_VMCNT(ahead + wh);
+        });
         asm volatile("" ::: "memory");
         const uint4 lo = *reinterpret_cast<const uint4*>(ring_w + ((2 * k) % kGramrSlots) * 1024 + lane * 16);
         uint4 hi = make_uint4(0u, 0u, 0u, 0u);

@@ -19,8 +19,16 @@ GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes)
     else fn = dma ? cd_gramr_kernel<3, 0, true, 4> : cd_gramr_kernel<3, 0, false, 4>;
   }
   else if (k <= 6) { *kr = 6; fn = dma ? cd_gramr_kernel<6, 0, true> : cd_gramr_kernel<6, 0, false>; }
-  else if (k <= 13) { *kr = 10; *kl = 3; fn = gramr_kernel_k13(dma); }
-  *lds_bytes = sizeof(float) * (size_t)*kl * kPackGroup + (dma ? (size_t)kGramrRingBytes : 0);
+  else if (k <= 13) {
+    // <10, 3> with a ring of 6 slots, or (SLIM_GPU_GRAMR_K13=11: A/B) <11, 2> with one of 10
+    const char* e = std::getenv("SLIM_GPU_GRAMR_K13");
+    const bool alt = e && std::atoi(e) == 11 && dma;
+    *kr = alt ? 11 : 10;
+    *kl = alt ? 2 : 3;
+    fn = gramr_kernel_k13(dma, alt);
+  }
+  *lds_bytes = sizeof(float) * (size_t)*kl * kPackGroup + (dma ? (size_t)gramr_ring_bytes(2) : 0);
+  if (k > 6 && k <= 13 && dma && *kl == 2) *lds_bytes = sizeof(float) * 2 * kPackGroup + (size_t)gramr_ring_bytes(4);
   return fn;
 }
 PackScanFn gram_pack_scan_fn() { return gram_pack_scan; }

@@ -2,5 +2,8 @@
 #include "cd_gramr.hpp"
 #include "gramr_inst.hpp"
 namespace slimamd {
-GramrFn gramr_kernel_k13(bool dma) { return dma ? cd_gramr_kernel<10, 3, true> : cd_gramr_kernel<10, 3, false>; }
+GramrFn gramr_kernel_k13(bool dma, bool alt) {
+  if (alt) return cd_gramr_kernel<11, 2, true, 2, 4>;
+  return dma ? cd_gramr_kernel<10, 3, true> : cd_gramr_kernel<10, 3, false>;
+}
 }  // namespace slimamd
