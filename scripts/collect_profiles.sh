@@ -21,7 +21,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 if [ -z "${SKIP_STATS:-}" ]; then
   export SLIM_GPU_TRACE=1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o run -- python $R/bench.py --steps ${STEPS:-2} --warmup ${WARMUP:-0} $ARGS > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o run -- python $R/bench.py --steps ${STEPS:-2} --warmup ${WARMUP:-0} --no-item-space $ARGS > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
   unset SLIM_GPU_TRACE
 fi
 for c in ${SKIP_PMC:+} $( [ -z "${SKIP_PMC:-}" ] && echo FETCH_SIZE WRITE_SIZE ); do

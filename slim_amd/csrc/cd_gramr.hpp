@@ -105,6 +105,7 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
   constexpr int KRA = KR > 0 ? KR : 1;
   constexpr int R0 = KR * kPackGroup;  // first rank held in LDS
   static_assert(KR <= 12, "register select covers 12 groups");
+  static_assert(KR + KL <= 16, "one base byte per group in a 16-byte load");
   extern __shared__ __attribute__((aligned(16))) float g_lds[];  // [KL][4][NT] float4: conflict-free
   __shared__ float s_gB[64];
   __shared__ int s_p, s_na;
@@ -139,19 +140,32 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
 #define SLIM_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
   char* const ring_w = reinterpret_cast<char*>(g_lds) + KL * kPackGroup * 4 + wave * (kGramrSlots * 1024);
   auto apply = [&](const uint8_t* __restrict__ plo, const uint8_t* __restrict__ phi,
-                   const uint8_t* __restrict__ ph2, const int hk, const int h2k,
+                   const uint8_t* __restrict__ ph2, const uint8_t* __restrict__ pbase, const int hk,
+                   const int h2k, const int cdiag, const int ediag, const float vdiag,
                    const float nd) __attribute__((always_inline)) {
+    // the base bytes of this thread's chunks (byte k: chunk tid + 512 k; 0 inside the hi prefix)
+    const uint4 bw = ld_off<uint4>(pbase, voff0);
+    const uint32_t bwords[4] = {bw.x, bw.y, bw.z, bw.w};
     // one group: decoded and added to what the thread owns
     auto consume = [&](auto kc, const uint4 lo, const uint4 hi) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
       float f[16];
       unpack16(lo, f);
+      {
+        const float bf = 16.0f * (float)((bwords[(k >> 2) & 3] >> (8 * (k & 3))) & 255u);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) f[e] += bf;  // (exact: integers below 2^24)
+      }
       if (k < hk) {
         unpack16_add(hi, 256.0f, f);
         if (k < h2k) {
           const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
           unpack16_add(ld_off<uint4>(ph2, vo), 65536.0f, f);
         }
+      }
+      if (tid + NT * k == cdiag) {  // the one chunk of the row that holds its diagonal entry
+#pragma unroll
+        for (int e = 0; e < 16; ++e) f[e] = e == ediag ? vdiag : f[e];
       }
       if constexpr (k < KR) {
         gramr_v16& g = gramr_reg<k>(gr);
@@ -459,12 +473,15 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         const uint8_t* __restrict__ plo = P.lo + (int64_t)row * P.ldb;
         const uint8_t* __restrict__ phi = P.hi + uni(P.hi_off[row]);
         const uint8_t* __restrict__ ph2 = P.hi2 + uni(P.hi2_off[row]);
-        // a visit's lane: the entry of the row its own coordinate needs (three byte loads issued
+        const uint8_t* __restrict__ pbase = P.base + (int64_t)row * kPackGroup;
+        // a visit's lane: the entry of the row its own coordinate needs (four byte loads issued
         // together, ahead of the row; behind a plane's prefix the lane reads byte 0 and drops it)
         const bool in1 = r < hk * kPackGroup, in2 = r < h2k * kPackGroup;
         const uint32_t b0 = plo[r], b1 = phi[in1 ? r : 0], b2 = ph2[in2 ? r : 0];
-        apply(plo, phi, ph2, hk, h2k, nd);  // (the one site that updates g)
-        float gsel = (float)b0;
+        const uint32_t b3 = pbase[((r >> 4) & (NT - 1)) * 16 + (r >> 13)];
+        const int rdiag = uni(rank_of[row]);
+        apply(plo, phi, ph2, pbase, hk, h2k, rdiag >> 4, rdiag & 15, uni(P.diag[row]), nd);  // (the one site that updates g)
+        float gsel = (float)b0 + 16.0f * (float)b3;
         gsel = in1 ? fmaf(256.0f, (float)b1, gsel) : gsel;
         gsel = in2 ? fmaf(65536.0f, (float)b2, gsel) : gsel;
         if (init_row) {  // (the byte model counts updates and folds; this row was the set-up)
@@ -569,7 +586,7 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         S.st_D[item] = (int64_t)s_D;
         S.st_U[item] = (int64_t)s_U;
         S.st_G[item] = nrows_read;  // (the engine reports the staging pass's G for the column)
-        S.st_B[item] = (int64_t)nrows_read * P.ldb + (int64_t)nhi16_read * 16;
+        S.st_B[item] = (int64_t)nrows_read * (P.ldb + 16 * (int64_t)(nchunks < NT ? nchunks : NT)) + (int64_t)nhi16_read * 16;
         S.st_err[item] = err;
         S.st_obj[item] = err + (float)reg;
       }

@@ -79,7 +79,7 @@ struct slimgpu_matrix {
   double G_build_ms = 0;
   // G as byte planes in popularity order (gram_pack.hpp), what cd_gramr.hpp streams: built from
   // the float G right after it, when every entry is a non-negative integer below 2^24
-  Buf ws_Glo, ws_Ghi, ws_Ghi2, ws_hioff, ws_hi2off, ws_hik, ws_hi2k, ws_rankof, ws_itemof;
+  Buf ws_Glo, ws_Ghi, ws_Ghi2, ws_Gbase, ws_Gdiag, ws_hioff, ws_hi2off, ws_hik, ws_hi2k, ws_rankof, ws_itemof;
   int64_t Gp_ldb = 0;
   int32_t Gp_nchunks = 0;
   bool Gp_ready = false, Gp_tried = false;
@@ -475,7 +475,7 @@ void destroy(slimgpu_matrix* m) {
        {&m->ws_order, &m->ws_cnt, &m->ws_off, &m->ws_stat_i, &m->ws_stat_l, &m->ws_stat_f,
         &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_xslab, &m->ws_ulist,
         &m->ws_trace, &m->ws_mailbox, &m->ws_part, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval,
-        &m->ws_gram, &m->ws_G, &m->ws_nunion, &m->ws_Glo, &m->ws_Ghi, &m->ws_Ghi2, &m->ws_hioff,
+        &m->ws_gram, &m->ws_G, &m->ws_nunion, &m->ws_Glo, &m->ws_Ghi, &m->ws_Ghi2, &m->ws_Gbase, &m->ws_Gdiag, &m->ws_hioff,
         &m->ws_hi2off, &m->ws_hik, &m->ws_hi2k, &m->ws_rankof, &m->ws_itemof})
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -878,8 +878,11 @@ bool pack_gram(slimgpu_matrix* m) {
   int32_t* d_flag = d_hik + ncols;
   HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), st));
   const float* dG = static_cast<const float*>(m->ws_G.p);
-  hipLaunchKernelGGL(gram_pack_scan_fn(), dim3(ncols), dim3(256), 0, st, dG, m->G_ld, ncols, d_item_of, d_hik,
-                     d_hi2k, d_flag);
+  // (SLIM_GPU_PACK_BASE=0: no per-chunk base bytes -- the first form of the planes, A/B runs)
+  int use_base = 1;
+  if (const char* e = std::getenv("SLIM_GPU_PACK_BASE")) use_base = std::atoi(e) != 0;
+  hipLaunchKernelGGL(gram_pack_scan_fn(), dim3(ncols), dim3(256), 0, st, dG, m->G_ld, ncols, d_item_of, nchunks,
+                     use_base, d_hik, d_hi2k, d_flag);
   HIP_TRY(hipGetLastError());
   std::vector<int32_t> hk((size_t)ncols + 1), h2k((size_t)ncols);
   HIP_TRY(hipMemcpyAsync(hk.data(), d_hik, sizeof(int32_t) * hk.size(), hipMemcpyDeviceToHost, st));
@@ -896,13 +899,17 @@ bool pack_gram(slimgpu_matrix* m) {
   }
   const int64_t ldb = (int64_t)nchunks * 16;
   // (a group of slack behind each pool: a lane outside a plane's prefix reads byte 0 of the plane)
-  const size_t need = (size_t)ncols * (size_t)ldb + (size_t)n1 + (size_t)n2 + 2 * (size_t)kPackGroup;
+  const size_t need = (size_t)ncols * ((size_t)ldb + kPackGroup) + (size_t)n1 + (size_t)n2 + 2 * (size_t)kPackGroup;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  if (need + (size_t(4) << 30) > free_b + m->ws_Glo.bytes + m->ws_Ghi.bytes + m->ws_Ghi2.bytes) return false;
+  if (need + (size_t(4) << 30) > free_b + m->ws_Glo.bytes + m->ws_Ghi.bytes + m->ws_Ghi2.bytes + m->ws_Gbase.bytes) return false;
   uint8_t* d_lo = ws_get<uint8_t>(m->ws_Glo, (size_t)ncols * (size_t)ldb);
   uint8_t* d_hi = ws_get<uint8_t>(m->ws_Ghi, (size_t)n1 + kPackGroup);
   uint8_t* d_hi2 = ws_get<uint8_t>(m->ws_Ghi2, (size_t)n2 + kPackGroup);
+  uint8_t* d_base = ws_get<uint8_t>(m->ws_Gbase, (size_t)ncols * kPackGroup);
+  HIP_TRY(hipMemsetAsync(d_base, 0, (size_t)ncols * kPackGroup, st));
+  float* d_diag = ws_get<float>(m->ws_Gdiag, (size_t)ncols);
+  HIP_TRY(hipMemsetAsync(d_diag, 0, sizeof(float) * (size_t)ncols, st));
   int64_t* d_off1 = ws_get<int64_t>(m->ws_hioff, (size_t)ncols);
   int64_t* d_off2 = ws_get<int64_t>(m->ws_hi2off, (size_t)ncols);
   HIP_TRY(hipMemcpyAsync(d_off1, off1.data(), sizeof(int64_t) * off1.size(), hipMemcpyHostToDevice, st));
@@ -910,16 +917,16 @@ bool pack_gram(slimgpu_matrix* m) {
   HIP_TRY(hipMemsetAsync(d_hi + n1, 0, kPackGroup, st));
   HIP_TRY(hipMemsetAsync(d_hi2 + n2, 0, kPackGroup, st));
   hipLaunchKernelGGL(gram_pack_write_fn(), dim3(ncols), dim3(256), 0, st, dG, m->G_ld, ncols, d_item_of, nchunks,
-                     d_lo, ldb, d_hi, d_off1, d_hik, d_hi2, d_off2, d_hi2k);
+                     d_lo, ldb, d_hi, d_off1, d_hik, d_hi2, d_off2, d_hi2k, d_base, d_diag);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));  // (off1 / off2 are locals)
   m->Gp_ldb = ldb;
   m->Gp_nchunks = nchunks;
-  m->Gp_bytes_per_row = (double)ldb + (double)(n1 + n2) / std::max(1, ncols);
+  m->Gp_bytes_per_row = (double)ldb + 16.0 * std::min(nchunks, kGramrNT) + (double)(n1 + n2) / std::max(1, ncols);
   m->Gp_ready = true;
   if (const char* te = std::getenv("SLIM_GPU_TRACE"); te && std::atoi(te) >= 1)
-    std::fprintf(stderr, "[trace] G packed: lo %.2f GB + hi %.2f GB + hi2 %.3f GB = %.3f bytes per entry, %.1f ms\n",
-                 (double)ncols * ldb * 1e-9, n1 * 1e-9, n2 * 1e-9,
+    std::fprintf(stderr, "[trace] G packed: lo %.2f GB + base %.2f GB + hi %.2f GB + hi2 %.3f GB = %.3f bytes per entry, %.1f ms\n",
+                 (double)ncols * ldb * 1e-9, (double)ncols * kPackGroup * 1e-9, n1 * 1e-9, n2 * 1e-9,
                  m->Gp_bytes_per_row / std::max(1, ncols), now_ms() - t0);
   return true;
 }
@@ -1627,6 +1634,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         P.hi2 = static_cast<const uint8_t*>(m->ws_Ghi2.p);
         P.hi2_off = static_cast<const int64_t*>(m->ws_hi2off.p);
         P.hi2_k = static_cast<const int32_t*>(m->ws_hi2k.p);
+        P.base = static_cast<const uint8_t*>(m->ws_Gbase.p);
+        P.diag = static_cast<const float*>(m->ws_Gdiag.p);
         P.rank_of = static_cast<const int32_t*>(m->ws_rankof.p);
         P.item_of = static_cast<const int32_t*>(m->ws_itemof.p);
         P.nchunks = m->Gp_nchunks;

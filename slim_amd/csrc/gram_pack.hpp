@@ -13,6 +13,18 @@
 //                     the row that needs them the plane simply ends
 //     hi2[hi2_k 8192] bits 16..23, likewise
 //
+// Behind that prefix a 16-rank chunk is stored RELATIVE to a per-chunk base: adjacent ranks are
+// about equally popular, so the 16 entries of a chunk spread by a few standard deviations of a
+// count around a common level (C4: ~270 +- 50) -- `lo` holds entry - 16 b, `base` the byte b
+// (floor(min / 16), at most 255); a chunk whose entries do not fit that (spread above 255, level
+// above 4080) extends the prefix.  Decoded as (float)(lo + 16 b + 256 hi + 65536 hi2), exactly.
+//
+// The DIAGONAL entry G_ii = |a_i|^2 is not a co-rating count of two different items: it sits at
+// the row's own rank and is as large as the row's largest entries (the first version kept it in the
+// planes, and the hi plane of an item of rank r then reached to r: 54-63 % of a row on C4 instead of
+// its popular head).  The planes hold a filler there (the chunk's base level) and the kernel puts
+// `diag[i]` in its place when it decodes that chunk.
+//
 // i.e. ~1.1-1.2 bytes per entry instead of 4, decoded exactly: (float)(lo + 256 hi + 65536 hi2)
 // is the float the unpacked G holds, so a kernel that reads the planes performs the very fmaf
 // sequence a kernel that reads the floats performs.  A matrix whose G holds anything else
@@ -40,28 +52,44 @@ struct GramPacked {
   const uint8_t* hi2;
   const int64_t* hi2_off;
   const int32_t* hi2_k;
+  const uint8_t* base;     // [ncols][8192]: byte [t * 16 + k] = b of chunk t + 512 k (0 inside the hi prefix)
+  const float* diag;       // [ncols]: G_ii, kept out of the planes (see below)
   const int32_t* rank_of;  // [ncols]
   const int32_t* item_of;  // [nchunks * 16]; -1 behind ncols
   int32_t nchunks;         // 16-rank chunks of a row: ceil(ncols / 16)
 };
 
 #ifdef SLIM_GRAM_PACK_KERNELS  // (defined by the one translation unit that owns the two kernels)
-// Pass 1, one workgroup per row: how many groups need the hi / hi2 plane, and whether the row can
-// be packed at all (flags[0] |= 1 otherwise).
+// Pass 1, one workgroup per row: how many groups need the hi / hi2 plane (use_base: chunks behind
+// the prefix may be stored relative to a base byte), and whether the row can be packed at all
+// (flags[0] |= 1 otherwise).
 __global__ __launch_bounds__(256) void gram_pack_scan(const float* __restrict__ G, int64_t ld, int ncols,
-                                                      const int32_t* __restrict__ item_of,
-                                                      int32_t* __restrict__ hi_k, int32_t* __restrict__ hi2_k,
-                                                      int32_t* __restrict__ flags) {
+                                                      const int32_t* __restrict__ item_of, int nchunks,
+                                                      int use_base, int32_t* __restrict__ hi_k,
+                                                      int32_t* __restrict__ hi2_k, int32_t* __restrict__ flags) {
   const int row = blockIdx.x;
   const float* __restrict__ g = G + (int64_t)row * ld;
-  int last1 = -1, last2 = -1;
+  int last1 = -1, last2 = -1;  // last chunk that needs the hi plane, last chunk with an entry >= 65536
   bool bad = false;
-  for (int r = threadIdx.x; r < ncols; r += 256) {
-    const float v = g[item_of[r]];
-    const int iv = (int)v;
-    if (!(v >= 0.0f && v < 16777216.0f) || (float)iv != v) bad = true;
-    if (iv >= 256) last1 = r;
-    if (iv >= 65536) last2 = r;
+  for (int c = threadIdx.x; c < nchunks; c += 256) {
+    int mn = 0x7fffffff, mx = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int it = item_of[c * 16 + e];
+      if (it >= 0) {
+        const float v = g[it];
+        const int iv = (int)v;
+        if (!(v >= 0.0f && v < 16777216.0f) || (float)iv != v) bad = true;
+        if (it != row) {  // (the diagonal is kept apart)
+          mn = iv < mn ? iv : mn;
+          mx = iv > mx ? iv : mx;
+        }
+      }
+    }
+    int b = (use_base && mn != 0x7fffffff) ? (mn >> 4) : 0;
+    b = b > 255 ? 255 : b;
+    if (mx - 16 * b > 255) last1 = c;
+    if (mx >= 65536) last2 = c;
   }
   __shared__ int s1, s2, sb;
   if (threadIdx.x == 0) {
@@ -75,8 +103,9 @@ __global__ __launch_bounds__(256) void gram_pack_scan(const float* __restrict__ 
   if (bad) atomicOr(&sb, 1);
   __syncthreads();
   if (threadIdx.x == 0) {
-    hi_k[row] = (s1 + kPackGroup) / kPackGroup;   // ceil((s1 + 1) / 8192); 0 when s1 == -1
-    hi2_k[row] = (s2 + kPackGroup) / kPackGroup;
+    constexpr int CG = kPackGroup / 16;  // chunks per group
+    hi_k[row] = (s1 + CG) / CG;          // ceil((s1 + 1) / 512); 0 when s1 == -1
+    hi2_k[row] = (s2 + CG) / CG;
     if (sb) atomicOr(flags, 1);
   }
 }
@@ -88,26 +117,43 @@ __global__ __launch_bounds__(256) void gram_pack_write(const float* __restrict__
                                                        uint8_t* __restrict__ hi, const int64_t* __restrict__ hi_off,
                                                        const int32_t* __restrict__ hi_k,
                                                        uint8_t* __restrict__ hi2, const int64_t* __restrict__ hi2_off,
-                                                       const int32_t* __restrict__ hi2_k) {
+                                                       const int32_t* __restrict__ hi2_k,
+                                                       uint8_t* __restrict__ base, float* __restrict__ diag) {
   const int row = blockIdx.x;
   const float* __restrict__ g = G + (int64_t)row * ld;
   const int n1 = hi_k[row] * (kPackGroup / 16), n2 = hi2_k[row] * (kPackGroup / 16);
   uint8_t* __restrict__ plo = lo + (int64_t)row * ldb;
   uint8_t* __restrict__ phi = hi + hi_off[row];
   uint8_t* __restrict__ ph2 = hi2 + hi2_off[row];
+  uint8_t* __restrict__ pb = base + (int64_t)row * kPackGroup;
   const int nmax = max(nchunks, max(n1, n2));
   for (int c = threadIdx.x; c < nmax; c += 256) {
     uint32_t w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0};
     if (c < nchunks) {
+      uint32_t iv[16];
+      uint32_t mn = 0xffffffffu;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int it = item_of[c * 16 + e];
-        const uint32_t iv = it >= 0 ? (uint32_t)(int)g[it] : 0u;
-        w0[e >> 2] |= (iv & 255u) << (8 * (e & 3));
-        w1[e >> 2] |= ((iv >> 8) & 255u) << (8 * (e & 3));
-        w2[e >> 2] |= ((iv >> 16) & 255u) << (8 * (e & 3));
+        iv[e] = it >= 0 ? (uint32_t)(int)g[it] : 0u;
+        if (it == row) diag[row] = g[it];
+        if (it >= 0 && it != row) mn = iv[e] < mn ? iv[e] : mn;
+      }
+      uint32_t b = 0;
+      if (c >= n1) {  // behind the prefix: relative to the chunk's base (pass 1 made sure it fits)
+        b = mn == 0xffffffffu ? 0u : (mn >> 4);
+        b = b > 255u ? 255u : b;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int it = item_of[c * 16 + e];
+        const uint32_t v = (it >= 0 && it != row) ? iv[e] - 16u * b : 0u;  // (diagonal: a filler)
+        w0[e >> 2] |= (v & 255u) << (8 * (e & 3));
+        w1[e >> 2] |= ((v >> 8) & 255u) << (8 * (e & 3));
+        w2[e >> 2] |= ((v >> 16) & 255u) << (8 * (e & 3));
       }
       *reinterpret_cast<uint4*>(plo + 16 * (int64_t)c) = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+      pb[(c & (kGramrNT - 1)) * 16 + (c / kGramrNT)] = (uint8_t)b;
     }
     if (c < n1) *reinterpret_cast<uint4*>(phi + 16 * (int64_t)c) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
     if (c < n2) *reinterpret_cast<uint4*>(ph2 + 16 * (int64_t)c) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
@@ -136,24 +182,6 @@ __device__ __forceinline__ void unpack16_add(const uint4 h, const float scale, f
     f[4 * j + 2] = fmaf(scale, (float)((w[j] >> 16) & 255u), f[4 * j + 2]);
     f[4 * j + 3] = fmaf(scale, (float)(w[j] >> 24), f[4 * j + 3]);
   }
-}
-
-// one entry: G[row][rank]
-__device__ __forceinline__ float packed_entry(const GramPacked& P, const int row, const int hk, const int h2k,
-                                              const uint8_t* __restrict__ plo, const uint8_t* __restrict__ phi,
-                                              const uint8_t* __restrict__ ph2, const int rank) {
-  float f = (float)plo[rank];
-  if (hk > 0) {  // (uniform branch; lanes behind the prefix read entry 0 and drop it)
-    const bool in1 = rank < hk * kPackGroup;
-    const float h = (float)phi[in1 ? rank : 0];
-    f = in1 ? fmaf(256.0f, h, f) : f;
-    if (h2k > 0) {
-      const bool in2 = rank < h2k * kPackGroup;
-      const float h2 = (float)ph2[in2 ? rank : 0];
-      f = in2 ? fmaf(65536.0f, h2, f) : f;
-    }
-  }
-  return f;
 }
 
 }  // namespace slimamd

@@ -15,9 +15,9 @@ using GramrFn = void (*)(const DevMatrix, const SolveArgs, const GramPacked);
 GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes);
 GramrFn gramr_kernel_k13(bool dma, bool alt);  // <10, 3>: its own translation unit (compiles beside the others)
 
-using PackScanFn = void (*)(const float*, int64_t, int, const int32_t*, int32_t*, int32_t*, int32_t*);
+using PackScanFn = void (*)(const float*, int64_t, int, const int32_t*, int, int, int32_t*, int32_t*, int32_t*);
 using PackWriteFn = void (*)(const float*, int64_t, int, const int32_t*, int, uint8_t*, int64_t, uint8_t*,
-                             const int64_t*, const int32_t*, uint8_t*, const int64_t*, const int32_t*);
+                             const int64_t*, const int32_t*, uint8_t*, const int64_t*, const int32_t*, uint8_t*, float*);
 PackScanFn gram_pack_scan_fn();
 PackWriteFn gram_pack_write_fn();
 
