@@ -93,15 +93,14 @@ __device__ __forceinline__ float gramr_sel(GramrRegs<KRA>& gr, const int k, cons
 // DMA: the row is streamed into a per-wavefront LDS ring by `global_load_lds_dwordx4` (LDS-DMA: no
 // VGPR holds data in flight) kGramrAhead groups ahead of the one being decoded, instead of GRP
 // register loads per round trip.
-// AH = groups requested ahead of the one consumed; the ring has 2 (AH + 1) slots of 1 KB per
-// wavefront (lo + hi per group in flight).
-constexpr int gramr_ring_bytes(int ah) { return (kGramrNT / 64) * 2 * (ah + 1) * 1024; }
+// AH = groups requested ahead of the one consumed; the ring has AH + 1 slots of 1 KB per wavefront.
+constexpr int gramr_ring_bytes(int ah) { return (kGramrNT / 64) * (ah + 1) * 1024; }
 
 template <int KR, int KL, bool DMA = false, int WPS = ((KR <= 2 && KL == 0) ? 4 : 2), int AH = 2>
 __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     const DevMatrix A, const SolveArgs S, const GramPacked P) {
   constexpr int NT = kGramrNT, K = KR + KL;
-  constexpr int kGramrAhead = AH, kGramrSlots = 2 * (AH + 1);
+  constexpr int kGramrAhead = AH, kGramrSlots = AH + 1;
   constexpr int KRA = KR > 0 ? KR : 1;
   constexpr int R0 = KR * kPackGroup;  // first rank held in LDS
   static_assert(KR <= 12, "register select covers 12 groups");
@@ -109,7 +108,8 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
   extern __shared__ __attribute__((aligned(16))) float g_lds[];  // [KL][4][NT] float4: conflict-free
   __shared__ float s_gB[64];
   __shared__ int s_p, s_na;
-  __shared__ unsigned long long s_D, s_U;
+  __shared__ unsigned long long s_D;   // sum of nnz(col i) over the active set: D of one sweep
+  __shared__ double s_e2[64], s_reg[64];  // the output pass's sums, per lane of wavefront 0
   __shared__ unsigned long long s_off;
   __shared__ int s_nz;
 
@@ -126,7 +126,6 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
   float4* const x4 = reinterpret_cast<float4*>(x);
   float4* const gl4 = reinterpret_cast<float4*>(g_lds);
   const int64_t* __restrict__ colptr = A.colptr;
-  const int32_t* __restrict__ rank_of = P.rank_of;
 
   GramrRegs<KRA> gr;
 
@@ -188,34 +187,41 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       }
     };
     if constexpr (DMA) {
-      // group k's lo lands in slot 2k % S, its hi (k < hk) in slot (2k + 1) % S of this wavefront's
-      // ring; lane L's 16 bytes at L * 16 of the slot -- every thread reads back what it asked for
+      // group k's `lo` lands in slot k % S of this wavefront's ring (S = AH + 1 slots of 1 KB);
+      // lane L's 16 bytes at L * 16 of the slot -- every thread reads back what it asked for.
+      // `hi` is rare behind the row's popular head (C4: half a group per row on average): the hi
+      // chunks of the first two groups are register loads issued BEFORE the ring's requests (older
+      // than all of them, so waiting for them drains nothing), later ones -- rows of the few very
+      // popular items -- are loaded when their group is decoded.
+      constexpr int S = kGramrAhead + 1;
+      uint4 h01[2];
+      static_for<2>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < K) {
+          if (k < hk) h01[k] = ld_off<uint4>(phi, min(voff0 + (uint32_t)(kPackGroup * k), vlast));
+        }
+      });
       auto request = [&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
         // (aux = SLIM_GRAMR_AUX: 2 = nt, a row is read once by one CU -- MI355X guide, "nt-weights")
-        __builtin_amdgcn_global_load_lds(plo + vo, ring_w + ((2 * k) % kGramrSlots) * 1024, 16, 0, SLIM_GRAMR_AUX);
-        if (k < hk)
-          __builtin_amdgcn_global_load_lds(phi + vo, ring_w + ((2 * k + 1) % kGramrSlots) * 1024, 16, 0,
-                                           SLIM_GRAMR_AUX);
+        __builtin_amdgcn_global_load_lds(plo + vo, ring_w + (k % S) * 1024, 16, 0, SLIM_GRAMR_AUX);
       };
       static_for<(kGramrAhead < K ? kGramrAhead : K)>([&](auto kc) __attribute__((always_inline)) { request(kc); });
       static_for<K>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         if constexpr (k + kGramrAhead < K) request(std::integral_constant<int, k + kGramrAhead>{});
-        // requests younger than group k's: one per group ahead, two where the group has a hi plane
-        // (loads complete in order: once at most that many are outstanding, group k has landed)
+        // loads complete in order: once at most `ahead` requests (the groups behind this one) are
+        // outstanding, group k has landed
         constexpr int ahead = (K - 1 - k) < kGramrAhead ? (K - 1 - k) : kGramrAhead;
-        int with_hi = hk - k - 1;
-        with_hi = with_hi < 0 ? 0 : (with_hi > ahead ? ahead : with_hi);
-        static_for<ahead + 1>([&](auto wc) __attribute__((always_inline)) {
-          constexpr int wh = decltype(wc)::value;
-          if (with_hi == wh) SLIM_VMCNT(ahead + wh);
-        });
+        SLIM_VMCNT(ahead);
         asm volatile("" ::: "memory");
-        const uint4 lo = *reinterpret_cast<const uint4*>(ring_w + ((2 * k) % kGramrSlots) * 1024 + lane * 16);
+        const uint4 lo = *reinterpret_cast<const uint4*>(ring_w + (k % S) * 1024 + lane * 16);
         uint4 hi = make_uint4(0u, 0u, 0u, 0u);
-        if (k < hk) hi = *reinterpret_cast<const uint4*>(ring_w + ((2 * k + 1) % kGramrSlots) * 1024 + lane * 16);
+        if (k < hk) {
+          if constexpr (k < 2) hi = h01[k];
+          else hi = ld_off<uint4>(phi, min(voff0 + (uint32_t)(kPackGroup * k), vlast));
+        }
         consume(kc, lo, hi);
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -277,7 +283,6 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       s_p = atomicAdd(S.queue, 1);
       s_na = 0;
       s_D = 0;
-      s_U = 0;
     }
     __syncthreads();
     const int p = s_p;
@@ -293,6 +298,7 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     {
       const float4* __restrict__ a4 = reinterpret_cast<const float4*>(arow);
       int na = 0;
+      int64_t dact = 0;
       for (int c = tid; c < n4; c += NT) {
         const float4 a = a4[c];
         const int i0 = c << 2;
@@ -307,9 +313,17 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         xs.w = a3 ? 0.0f : kInactive;
         na += (int)a0 + (int)a1 + (int)a2 + (int)a3;
         x4[c] = xs;
+        // (SURVEY 8(d)'s D: every sweep visits the whole active set, so D = sweeps x this sum)
+        if (a0 | a1 | a2 | a3) {
+          const int64_t c0 = colptr[i0], c1 = colptr[i0 + 1];
+          const int64_t c2 = i0 + 2 <= ncols ? colptr[i0 + 2] : c1, c3 = i0 + 3 <= ncols ? colptr[i0 + 3] : c2;
+          const int64_t c4 = i0 + 4 <= ncols ? colptr[i0 + 4] : c3;
+          dact += (a0 ? c1 - c0 : 0) + (a1 ? c2 - c1 : 0) + (a2 ? c3 - c2 : 0) + (a3 ? c4 - c3 : 0);
+        }
       }
       na = (int)wave_sum((float)na);  // (< 2^24: exact)
       if (lane == 0 && na) atomicAdd(&s_na, na);
+      if (dact) atomicAdd(&s_D, (unsigned long long)dact);
     }
     // -- warm start (estimate.c:453-464): previous coefficients of the coordinates active now (a
     //    negative value ends up 0 there: the flag-clearing loop resets every x < 0)
@@ -341,7 +355,6 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       maxit = cap < (int64_t)S.maxniters ? (int)cap : S.maxniters;
     }
     int niters = 0, conv = 0;
-    uint32_t Dq = 0, Uq = 0;  // SURVEY.md 8(d) counters, per lane and sweep (same in every wave)
     nrows_read = 0;
     nhi16_read = 0;
 
@@ -352,13 +365,20 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     //            warm-start fold g -= x_j G[j, :] (cd.c:108-110 in item space)
     //   phase 1  sweeps (cd.c:112-139): a pass = one batch of 64 visits
     //   phase 2  output (estimate.c:477-505): a pass = 64 item ids, ascending
+    if (wave == 0) {
+      s_e2[lane] = 0.0;
+      s_reg[lane] = 0.0;
+    }
     int phase = 0;
     bool init_row = true;
     int t = 0, p0 = 0;      // sweep, first position of the batch
     float dlt = 0.0f;
     PermCtx pc = perm_make(1u, 0u);
-    int i_n = 0, r_n = 0, len_n = 0;  // header of the NEXT batch (loaded one batch ahead: its three
-    float xi_n = kInactive, sq_n = 0.0f, cn_n = 0.0f;  // dependent loads overlap this batch's updates)
+    // header of the NEXT batch, loaded one batch ahead (its dependent loads overlap this batch's
+    // updates): the lane's item, its x and its row record {rank | hi_k | hi2_k, hi group, nnz, |a|^2}
+    int i_n = 0;
+    uint4 m_n = make_uint4(0u, 0u, 0u, 0u);
+    float xi_n = kInactive;
     auto header = [&](const int q0) __attribute__((always_inline)) {
       const int pos = q0 + lane;
       i_n = 0;
@@ -367,35 +387,26 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         i_n = ul[perm_index(pc, (uint32_t)pos)];
         xi_n = x[i_n];
       }
-      r_n = rank_of[i_n];
-      sq_n = 0.0f;
-      cn_n = 0.0f;
-      len_n = 0;
-      if (tile_active(xi_n)) {
-        sq_n = A.csq[i_n];
-        cn_n = A.cnorm[i_n];
-        len_n = (int)(colptr[i_n + 1] - colptr[i_n]);
-      }
+      m_n = P.meta[i_n];
     };
     int ib = 0, wpos = 0, nz = 0;  // output pass
     unsigned long long off = 0;
     bool fits = false;
-    double e2 = 0.0, reg = 0.0;
+    unsigned long long Uu = 0;  // SURVEY 8(d)'s U: nnz of the columns whose coefficient moved (uniform)
 
     for (;;) {  // passes
       // -- what the lanes of this pass are about
       bool want = false;
-      int r = 0, i = 0, len = 0;
-      float xi = kInactive, sq = 0.0f, cn = 0.0f;
+      int r = 0, i = 0;
+      uint4 mrow = make_uint4(0u, 0u, 0u, 0u);  // row record of the lane's item: read by readlane at an update
+      float xi = kInactive;
       bool part = false, keep = false;
       uint64_t mkeep = 0;
       if (phase == 1) {
         i = i_n;
-        r = r_n;
-        len = len_n;
+        r = (int)(m_n.x & 0x1FFFFu);
+        mrow = m_n;
         xi = xi_n;
-        sq = sq_n;
-        cn = cn_n;
         part = tile_active(xi);
         if (p0 + 64 < nunion) header(p0 + 64);
         want = part;
@@ -404,14 +415,15 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         xi = i < ncols ? x[i] : kInactive;
         const bool act = tile_active(xi);
         keep = act && fabsf(xi) > kEps;
-        if (act) reg += 0.5 * (double)l2 * (double)xi * (double)xi + (double)l1 * (double)fabsf(xi);
+        if (act && wave == 0)
+          s_reg[lane] += 0.5 * (double)l2 * (double)xi * (double)xi + (double)l1 * (double)fabsf(xi);
         mkeep = __ballot(keep);
         if (mkeep == 0) {  // nothing kept among these 64 ids
           ib += 64;
           if (ib >= ncols) break;
           continue;
         }
-        r = keep ? rank_of[i] : 0;
+        r = keep ? (int)(P.meta[i].x & 0x1FFFFu) : 0;
         want = keep;
       }
       const float g0 = fetch_g(want, r);  // (the one site that reads g out)
@@ -419,12 +431,12 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       uint64_t pend = 0;
       if (phase == 1) {
         pend = __ballot(part);
-        Dq += (uint32_t)len;
       }
       // -- the rows this pass applies
       for (;;) {
         int row = 0;
         float nd = 0.0f;
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);  // {rank | hi_k << 17 | hi2_k << 21, hi group, hi2 group, G_ii}
         if (phase == 0) {
           bool have = false;
           if (init_row) {
@@ -450,6 +462,10 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         } else if (phase == 1) {
           if (pend == 0) break;
           const float xeff = (xi > kEps || xi < -kEps) ? xi : 0.0f;
+          // |a_i|^2 from the record (the planes are only built when it equals csq[i] and its root
+          // equals cnorm[i], gram_pack_meta) -- setup.c:130's rounded norm, squared again (cd.c:127)
+          const float sq = __uint_as_float(mrow.w);
+          const float cn = sqrtf(sq);
           const float num = gi + xeff * sq;
           const float nx = num > l1 ? (num - l1) / (cn * cn + l2) : 0.0f;
           const float neff = (nx > kEps || nx < -kEps) ? nx : 0.0f;
@@ -463,24 +479,37 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
           if (wave == 0 && lane == f) x[i] = nx;
           pend = f == 63 ? 0ull : (pend & ~((2ull << f) - 1ull));
           if (d_f == 0.0f) continue;  // (a change below the epsilon of cd.c:27 moves no g)
-          if (lane == f) Uq += (uint32_t)len;
           row = lane_bcast(i, f);
           nd = -d_f;
+          // (the row's record came with the batch header: no dependent load between the decision
+          // and the first request of the row)
+          rec.x = (uint32_t)lane_bcast((int)mrow.x, f);
+          rec.y = (uint32_t)lane_bcast((int)mrow.y, f);
+          rec.z = (uint32_t)lane_bcast((int)mrow.z, f);
+          rec.w = (uint32_t)lane_bcast((int)mrow.w, f);
+          Uu += (unsigned long long)rec.z;
         } else {
           break;
         }
-        const int hk = uni(P.hi_k[row]), h2k = uni(P.hi2_k[row]);
+        if (phase == 0) {
+          const uint4 mr = P.meta[row];
+          rec.x = uni(mr.x);
+          rec.y = uni(mr.y);
+          rec.z = uni(mr.z);
+          rec.w = uni(mr.w);
+        }
+        const int hk = (int)((rec.x >> 17) & 15u), h2k = (int)((rec.x >> 21) & 15u);
         const uint8_t* __restrict__ plo = P.lo + (int64_t)row * P.ldb;
-        const uint8_t* __restrict__ phi = P.hi + uni(P.hi_off[row]);
-        const uint8_t* __restrict__ ph2 = P.hi2 + uni(P.hi2_off[row]);
+        const uint8_t* __restrict__ phi = P.hi + (int64_t)rec.y * kPackGroup;
+        const uint8_t* __restrict__ ph2 = P.hi2 + (h2k > 0 ? uni(P.hi2_off[row]) : 0);
         const uint8_t* __restrict__ pbase = P.base + (int64_t)row * kPackGroup;
         // a visit's lane: the entry of the row its own coordinate needs (four byte loads issued
         // together, ahead of the row; behind a plane's prefix the lane reads byte 0 and drops it)
         const bool in1 = r < hk * kPackGroup, in2 = r < h2k * kPackGroup;
         const uint32_t b0 = plo[r], b1 = phi[in1 ? r : 0], b2 = ph2[in2 ? r : 0];
         const uint32_t b3 = pbase[((r >> 4) & (NT - 1)) * 16 + (r >> 13)];
-        const int rdiag = uni(rank_of[row]);
-        apply(plo, phi, ph2, pbase, hk, h2k, rdiag >> 4, rdiag & 15, uni(P.diag[row]), nd);  // (the one site that updates g)
+        const int rdiag = (int)(rec.x & 0x1FFFFu);
+        apply(plo, phi, ph2, pbase, hk, h2k, rdiag >> 4, rdiag & 15, __uint_as_float(rec.w), nd);  // (the one site that updates g)
         float gsel = (float)b0 + 16.0f * (float)b3;
         gsel = in1 ? fmaf(256.0f, (float)b1, gsel) : gsel;
         gsel = in2 ? fmaf(65536.0f, (float)b2, gsel) : gsel;
@@ -496,12 +525,6 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       if (phase == 1) {
         p0 += 64;
         if (p0 < nunion) continue;
-        if (wave == 0) {  // (a lane's share of one sweep fits 32 bits; the totals do not)
-          if (Dq) atomicAdd(&s_D, (unsigned long long)Dq);
-          if (Uq) atomicAdd(&s_U, (unsigned long long)Uq);
-        }
-        Dq = 0;
-        Uq = 0;
         if (dlt < S.opt_tol) {  // cd.c:135-138
           conv = 1;
           niters = t + 1;
@@ -510,7 +533,7 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         }
       } else if (phase == 2) {
         if (keep) {
-          e2 += (double)xi * ((double)arow[i] + (double)g0);
+          if (wave == 0) s_e2[lane] += (double)xi * ((double)arow[i] + (double)g0);
           if (fits && wave == 0) {
             const int64_t dst = (int64_t)off + wpos + __popcll(mkeep & ((1ull << lane) - 1ull));
             S.out_ind[dst] = i;
@@ -571,6 +594,7 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     // ||y - A x||^2 = |a_iC|^2 - sum_i x_i (aTy_i + g_i) over the kept coefficients (every
     // wavefront formed the same sums; wavefront 0 reports)
     if (wave == 0) {
+      double e2 = s_e2[lane], reg = s_reg[lane];
       for (int o = 32; o > 0; o >>= 1) {
         e2 += __shfl_xor(e2, o);
         reg += __shfl_xor(reg, o);
@@ -583,8 +607,8 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         S.st_na[item] = s_na;
         S.st_sweeps[item] = niters;
         S.st_conv[item] = conv;
-        S.st_D[item] = (int64_t)s_D;
-        S.st_U[item] = (int64_t)s_U;
+        S.st_D[item] = (int64_t)s_D * (int64_t)(conv ? niters : maxit);  // (sweeps that ran)
+        S.st_U[item] = (int64_t)Uu;
         S.st_G[item] = nrows_read;  // (the engine reports the staging pass's G for the column)
         S.st_B[item] = (int64_t)nrows_read * (P.ldb + 16 * (int64_t)(nchunks < NT ? nchunks : NT)) + (int64_t)nhi16_read * 16;
         S.st_err[item] = err;

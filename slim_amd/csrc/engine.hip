@@ -79,7 +79,7 @@ struct slimgpu_matrix {
   double G_build_ms = 0;
   // G as byte planes in popularity order (gram_pack.hpp), what cd_gramr.hpp streams: built from
   // the float G right after it, when every entry is a non-negative integer below 2^24
-  Buf ws_Glo, ws_Ghi, ws_Ghi2, ws_Gbase, ws_Gdiag, ws_hioff, ws_hi2off, ws_hik, ws_hi2k, ws_rankof, ws_itemof;
+  Buf ws_Glo, ws_Ghi, ws_Ghi2, ws_Gbase, ws_Gdiag, ws_Gmeta, ws_hioff, ws_hi2off, ws_hik, ws_hi2k, ws_rankof, ws_itemof;
   int64_t Gp_ldb = 0;
   int32_t Gp_nchunks = 0;
   bool Gp_ready = false, Gp_tried = false;
@@ -475,7 +475,7 @@ void destroy(slimgpu_matrix* m) {
        {&m->ws_order, &m->ws_cnt, &m->ws_off, &m->ws_stat_i, &m->ws_stat_l, &m->ws_stat_f,
         &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_xslab, &m->ws_ulist,
         &m->ws_trace, &m->ws_mailbox, &m->ws_part, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval,
-        &m->ws_gram, &m->ws_G, &m->ws_nunion, &m->ws_Glo, &m->ws_Ghi, &m->ws_Ghi2, &m->ws_Gbase, &m->ws_Gdiag, &m->ws_hioff,
+        &m->ws_gram, &m->ws_G, &m->ws_nunion, &m->ws_Glo, &m->ws_Ghi, &m->ws_Ghi2, &m->ws_Gbase, &m->ws_Gdiag, &m->ws_Gmeta, &m->ws_hioff,
         &m->ws_hi2off, &m->ws_hik, &m->ws_hi2k, &m->ws_rankof, &m->ws_itemof})
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -919,7 +919,14 @@ bool pack_gram(slimgpu_matrix* m) {
   hipLaunchKernelGGL(gram_pack_write_fn(), dim3(ncols), dim3(256), 0, st, dG, m->G_ld, ncols, d_item_of, nchunks,
                      d_lo, ldb, d_hi, d_off1, d_hik, d_hi2, d_off2, d_hi2k, d_base, d_diag);
   HIP_TRY(hipGetLastError());
+  uint4* d_meta = ws_get<uint4>(m->ws_Gmeta, (size_t)ncols);
+  hipLaunchKernelGGL(gram_pack_meta_fn(), dim3((ncols + 255) / 256), dim3(256), 0, st, ncols, d_rank_of, d_hik,
+                     d_hi2k, d_off1, d_diag, m->d_colptr, m->d_csq, m->d_cnorm, d_meta, d_flag);
+  HIP_TRY(hipGetLastError());
+  int32_t meta_flag = 0;
+  HIP_TRY(hipMemcpyAsync(&meta_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));  // (off1 / off2 are locals)
+  if (meta_flag & 2) return false;    // |a_i|^2 of the planes is not the column view's: float kernels
   m->Gp_ldb = ldb;
   m->Gp_nchunks = nchunks;
   m->Gp_bytes_per_row = (double)ldb + 16.0 * std::min(nchunks, kGramrNT) + (double)(n1 + n2) / std::max(1, ncols);
@@ -1636,6 +1643,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         P.hi2_k = static_cast<const int32_t*>(m->ws_hi2k.p);
         P.base = static_cast<const uint8_t*>(m->ws_Gbase.p);
         P.diag = static_cast<const float*>(m->ws_Gdiag.p);
+        P.meta = static_cast<const uint4*>(m->ws_Gmeta.p);
         P.rank_of = static_cast<const int32_t*>(m->ws_rankof.p);
         P.item_of = static_cast<const int32_t*>(m->ws_itemof.p);
         P.nchunks = m->Gp_nchunks;

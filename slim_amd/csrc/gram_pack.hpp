@@ -54,6 +54,9 @@ struct GramPacked {
   const int32_t* hi2_k;
   const uint8_t* base;     // [ncols][8192]: byte [t * 16 + k] = b of chunk t + 512 k (0 inside the hi prefix)
   const float* diag;       // [ncols]: G_ii, kept out of the planes (see below)
+  const uint4* meta;       // [ncols]: what the solver needs of a row in ONE 16-byte record, so that a lane
+                           // can load it with its batch header: {rank | hi_k << 17 | hi2_k << 21,
+                           // hi_off / 8192, nnz of the column, bits of |a_i|^2 = G_ii}
   const int32_t* rank_of;  // [ncols]
   const int32_t* item_of;  // [nchunks * 16]; -1 behind ncols
   int32_t nchunks;         // 16-rank chunks of a row: ceil(ncols / 16)
@@ -157,6 +160,23 @@ __global__ __launch_bounds__(256) void gram_pack_write(const float* __restrict__
     }
     if (c < n1) *reinterpret_cast<uint4*>(phi + 16 * (int64_t)c) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
     if (c < n2) *reinterpret_cast<uint4*>(ph2 + 16 * (int64_t)c) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+  }
+}
+
+// the row records (after pass 2).  The solver takes |a_i|^2 and its root from the record instead
+// of csq / cnorm: flags[0] |= 2 (and the planes are not used) unless G_ii == csq[i] and
+// sqrtf(csq[i]) == cnorm[i] bit for bit -- true for the integer-valued matrices that can be packed.
+__global__ void gram_pack_meta(int ncols, const int32_t* __restrict__ rank_of, const int32_t* __restrict__ hi_k,
+                               const int32_t* __restrict__ hi2_k, const int64_t* __restrict__ hi_off,
+                               const float* __restrict__ diag, const int64_t* __restrict__ colptr,
+                               const float* __restrict__ csq, const float* __restrict__ cnorm,
+                               uint4* __restrict__ meta, int32_t* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncols) {
+    if (diag[i] != csq[i] || sqrtf(csq[i]) != cnorm[i]) atomicOr(flags, 2);
+    meta[i] = make_uint4((uint32_t)rank_of[i] | ((uint32_t)hi_k[i] << 17) | ((uint32_t)hi2_k[i] << 21),
+                         (uint32_t)(hi_off[i] / kPackGroup), (uint32_t)(colptr[i + 1] - colptr[i]),
+                         __float_as_uint(csq[i]));
   }
 }
 

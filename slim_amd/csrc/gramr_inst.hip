@@ -7,6 +7,7 @@ namespace slimamd {
 GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes) {
   const int k = (nchunks + kGramrNT - 1) / kGramrNT;
   *kl = 0;
+  int ring_ah = 2;
   GramrFn fn = nullptr;
   if (k <= 1) { *kr = 1; fn = dma ? cd_gramr_kernel<1, 0, true> : cd_gramr_kernel<1, 0, false>; }
   else if (k <= 3) {
@@ -20,17 +21,18 @@ GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes)
   }
   else if (k <= 6) { *kr = 6; fn = dma ? cd_gramr_kernel<6, 0, true> : cd_gramr_kernel<6, 0, false>; }
   else if (k <= 13) {
-    // <10, 3> with a ring of 6 slots, or (SLIM_GPU_GRAMR_K13=11: A/B) <11, 2> with one of 10
+    // <10, 3>; the ring is 4 slots deep (SLIM_GPU_GRAMR_K13=2: 3 slots -- A/B: 4.40 against 4.33 s)
     const char* e = std::getenv("SLIM_GPU_GRAMR_K13");
-    const bool alt = e && std::atoi(e) == 11 && dma;
-    *kr = alt ? 11 : 10;
-    *kl = alt ? 2 : 3;
-    fn = gramr_kernel_k13(dma, alt);
+    const bool shallow = e && std::atoi(e) == 2;
+    *kr = 10;
+    *kl = 3;
+    ring_ah = shallow ? 2 : 3;
+    fn = gramr_kernel_k13(dma, !shallow);
   }
-  *lds_bytes = sizeof(float) * (size_t)*kl * kPackGroup + (dma ? (size_t)gramr_ring_bytes(2) : 0);
-  if (k > 6 && k <= 13 && dma && *kl == 2) *lds_bytes = sizeof(float) * 2 * kPackGroup + (size_t)gramr_ring_bytes(4);
+  *lds_bytes = sizeof(float) * (size_t)*kl * kPackGroup + (dma ? (size_t)gramr_ring_bytes(ring_ah) : 0);
   return fn;
 }
 PackScanFn gram_pack_scan_fn() { return gram_pack_scan; }
 PackWriteFn gram_pack_write_fn() { return gram_pack_write; }
+PackMetaFn gram_pack_meta_fn() { return gram_pack_meta; }
 }  // namespace slimamd

@@ -20,5 +20,8 @@ using PackWriteFn = void (*)(const float*, int64_t, int, const int32_t*, int, ui
                              const int64_t*, const int32_t*, uint8_t*, const int64_t*, const int32_t*, uint8_t*, float*);
 PackScanFn gram_pack_scan_fn();
 PackWriteFn gram_pack_write_fn();
+using PackMetaFn = void (*)(int, const int32_t*, const int32_t*, const int32_t*, const int64_t*, const float*,
+                            const int64_t*, const float*, const float*, uint4*, int32_t*);
+PackMetaFn gram_pack_meta_fn();
 
 }  // namespace slimamd

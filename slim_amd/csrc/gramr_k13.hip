@@ -3,7 +3,7 @@
 #include "gramr_inst.hpp"
 namespace slimamd {
 GramrFn gramr_kernel_k13(bool dma, bool alt) {
-  if (alt) return cd_gramr_kernel<11, 2, true, 2, 4>;
+  if (alt) return cd_gramr_kernel<10, 3, true, 2, 3>;
   return dma ? cd_gramr_kernel<10, 3, true> : cd_gramr_kernel<10, 3, false>;
 }
 }  // namespace slimamd
