@@ -40,6 +40,9 @@
 #ifndef SLIM_GRAMR_AUX
 #define SLIM_GRAMR_AUX 0
 #endif
+#ifndef SLIM_GRAMR_PROF
+#define SLIM_GRAMR_PROF 0
+#endif
 
 namespace slimamd {
 
@@ -93,20 +96,21 @@ __device__ __forceinline__ float gramr_sel(GramrRegs<KRA>& gr, const int k, cons
 // DMA: the row is streamed into a per-wavefront LDS ring by `global_load_lds_dwordx4` (LDS-DMA: no
 // VGPR holds data in flight) kGramrAhead groups ahead of the one being decoded, instead of GRP
 // register loads per round trip.
-// AH = groups requested ahead of the one consumed; the ring has AH + 1 slots of 1 KB per wavefront.
-constexpr int gramr_ring_bytes(int ah) { return (kGramrNT / 64) * (ah + 1) * 1024; }
+// AH = groups requested ahead of the one consumed; the ring has AH + 1 slots of 1 KB per wavefront,
+// and one more slot takes the row's base bytes.
+constexpr int gramr_ring_bytes(int ah) { return (kGramrNT / 64) * (ah + 2) * 1024; }
 
 template <int KR, int KL, bool DMA = false, int WPS = ((KR <= 2 && KL == 0) ? 4 : 2), int AH = 2>
 __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     const DevMatrix A, const SolveArgs S, const GramPacked P) {
   constexpr int NT = kGramrNT, K = KR + KL;
-  constexpr int kGramrAhead = AH, kGramrSlots = AH + 1;
+  constexpr int kGramrAhead = AH, kGramrSlots = AH + 2;  // (ring + one slot for the base bytes)
   constexpr int KRA = KR > 0 ? KR : 1;
   constexpr int R0 = KR * kPackGroup;  // first rank held in LDS
   static_assert(KR <= 12, "register select covers 12 groups");
   static_assert(KR + KL <= 16, "one base byte per group in a 16-byte load");
   extern __shared__ __attribute__((aligned(16))) float g_lds[];  // [KL][4][NT] float4: conflict-free
-  __shared__ float s_gB[64];
+  __shared__ float s_gB[2][64];  // the batch's g, double-buffered: one barrier per batch (fetch_g)
   __shared__ int s_p, s_na;
   __shared__ unsigned long long s_D;   // sum of nnz(col i) over the active set: D of one sweep
   __shared__ double s_e2[64], s_reg[64];  // the output pass's sums, per lane of wavefront 0
@@ -138,31 +142,63 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
   // s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
 #define SLIM_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
   char* const ring_w = reinterpret_cast<char*>(g_lds) + KL * kPackGroup * 4 + wave * (kGramrSlots * 1024);
+#if SLIM_GRAMR_PROF
+  unsigned long long pt_first_v = 0, pt_mark_v = 0;
+  unsigned long long* const pt_first_p = &pt_first_v;
+  unsigned long long* const pt_mark_p = &pt_mark_v;
+#endif
   auto apply = [&](const uint8_t* __restrict__ plo, const uint8_t* __restrict__ phi,
                    const uint8_t* __restrict__ ph2, const uint8_t* __restrict__ pbase, const int hk,
                    const int h2k, const int cdiag, const int ediag, const float vdiag,
                    const float nd) __attribute__((always_inline)) {
     // the base bytes of this thread's chunks (byte k: chunk tid + 512 k; 0 inside the hi prefix)
-    const uint4 bw = ld_off<uint4>(pbase, voff0);
-    const uint32_t bwords[4] = {bw.x, bw.y, bw.z, bw.w};
+    const int kdiag = cdiag / NT, tdiag = cdiag % NT;  // (uniform: the group test is a scalar branch)
+    // (with the ring they come by LDS-DMA too, ahead of the row's first group: as a register load
+    // the scheduler started on group 0's base byte between the ring's first requests, and the wait it
+    // put there drained the requests already made -- an exposed latency per row before the ring was
+    // even full)
+    uint32_t bwords[4];
+    if constexpr (DMA) {
+      __builtin_amdgcn_global_load_lds(pbase + voff0, ring_w + (kGramrAhead + 1) * 1024, 16, 0, 0);
+    } else {
+      const uint4 bw = ld_off<uint4>(pbase, voff0);
+      bwords[0] = bw.x;
+      bwords[1] = bw.y;
+      bwords[2] = bw.z;
+      bwords[3] = bw.w;
+    }
     // one group: decoded and added to what the thread owns
-    auto consume = [&](auto kc, const uint4 lo, const uint4 hi) __attribute__((always_inline)) {
+    // (the hi chunk is fetched by `hi_of` INSIDE the branch that uses it: with the load in one block
+    // and the use in another, the compiler's wait-count state at the join says "maybe pending", and
+    // before the next write of those registers it waits for EVERYTHING outstanding -- the whole ring,
+    // on every group of every row whether it has a hi chunk or not)
+    auto consume = [&](auto kc, const uint4 lo, auto&& hi_of) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
       float f[16];
       unpack16(lo, f);
       {
+        // (exact: integers below 2^24.  The pairs pass through an empty asm: left alone, the optimizer
+        // adds the base in integer and converts afterwards -- 16 byte-select adds + 16 conversions
+        // instead of 16 byte conversions + 8 packed float adds)
+        typedef float gramr_v2 __attribute__((ext_vector_type(2)));
         const float bf = 16.0f * (float)((bwords[(k >> 2) & 3] >> (8 * (k & 3))) & 255u);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) f[e] += bf;  // (exact: integers below 2^24)
+        for (int e = 0; e < 16; e += 2) {
+          gramr_v2 v = {f[e], f[e + 1]};
+          asm volatile("" : "+v"(v));
+          v += (gramr_v2)(bf);
+          f[e] = v.x;
+          f[e + 1] = v.y;
+        }
       }
       if (k < hk) {
-        unpack16_add(hi, 256.0f, f);
+        unpack16_add(hi_of(), 256.0f, f);
         if (k < h2k) {
           const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
           unpack16_add(ld_off<uint4>(ph2, vo), 65536.0f, f);
         }
       }
-      if (tid + NT * k == cdiag) {  // the one chunk of the row that holds its diagonal entry
+      if (k == kdiag && tid == tdiag) {  // the one chunk of the row that holds its diagonal entry
 #pragma unroll
         for (int e = 0; e < 16; ++e) f[e] = e == ediag ? vdiag : f[e];
       }
@@ -216,13 +252,21 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         constexpr int ahead = (K - 1 - k) < kGramrAhead ? (K - 1 - k) : kGramrAhead;
         SLIM_VMCNT(ahead);
         asm volatile("" ::: "memory");
-        const uint4 lo = *reinterpret_cast<const uint4*>(ring_w + (k % S) * 1024 + lane * 16);
-        uint4 hi = make_uint4(0u, 0u, 0u, 0u);
-        if (k < hk) {
-          if constexpr (k < 2) hi = h01[k];
-          else hi = ld_off<uint4>(phi, min(voff0 + (uint32_t)(kPackGroup * k), vlast));
+        if constexpr (k == 0) {  // (requested before group 0: landed with it)
+          const uint4 bw = *reinterpret_cast<const uint4*>(ring_w + (kGramrAhead + 1) * 1024 + lane * 16);
+          bwords[0] = bw.x;
+          bwords[1] = bw.y;
+          bwords[2] = bw.z;
+          bwords[3] = bw.w;
         }
-        consume(kc, lo, hi);
+#if SLIM_GRAMR_PROF
+        if constexpr (k == 0) *pt_first_p += __builtin_readcyclecounter() - *pt_mark_p;
+#endif
+        const uint4 lo = *reinterpret_cast<const uint4*>(ring_w + (k % S) * 1024 + lane * 16);
+        consume(kc, lo, [&]() __attribute__((always_inline)) -> uint4 {
+          if constexpr (k < 2) return h01[k];
+          else return ld_off<uint4>(phi, min(voff0 + (uint32_t)(kPackGroup * k), vlast));
+        });
         __builtin_amdgcn_sched_barrier(0);
       });
     } else {
@@ -241,7 +285,8 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         __builtin_amdgcn_sched_barrier(0);  // (the loads of ONE group of GRP chunks in flight, not of all)
         static_for<GRP>([&](auto uc) __attribute__((always_inline)) {
           constexpr int u = decltype(uc)::value, k = k0 + u;
-          if constexpr (k < K) consume(std::integral_constant<int, k>{}, l[u], h[u]);
+          if constexpr (k < K)
+            consume(std::integral_constant<int, k>{}, l[u], [&]() __attribute__((always_inline)) -> uint4 { return h[u]; });
           __builtin_amdgcn_sched_barrier(0);
         });
       });
@@ -257,25 +302,30 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
   };
 
   // g of the lanes' coordinates (rank r, wanted where `want`): every wavefront exports the entries
-  // its threads hold in registers (a wave-uniform register select per entry) to one 64-float LDS
-  // line, entries of the LDS groups are copied there too -- nobody may read g_lds once the first
-  // wavefront has started applying a batch's rows.  Called by all threads; two barriers.
+  // ITS threads hold -- in registers (a wave-uniform register select per entry) or in the LDS groups
+  // (program order inside a wavefront: no other wavefront's updates are read) -- to a 64-float LDS
+  // line.  Called by all threads; ONE barrier: the line is double-buffered, and a buffer written in
+  // call n was last read right behind the barrier of call n - 2, i.e. before its readers reached the
+  // barrier of call n - 1.
+  int gb_par = 0;
   auto fetch_g = [&](const bool want, const int r) __attribute__((always_inline)) -> float {
-    __syncthreads();  // earlier row updates are in LDS; s_gB is free
+    float* const gb = s_gB[gb_par];
+    gb_par ^= 1;
     const bool in_lds = r >= R0;
+    const bool my_wave = (((r >> 4) & (NT - 1)) >> 6) == wave;
     if (KR > 0) {
-      uint64_t mine = __ballot(want && !in_lds && (((r >> 4) & (NT - 1)) >> 6) == wave);
+      uint64_t mine = __ballot(want && !in_lds && my_wave);
       while (mine) {
         const int b = __builtin_ctzll(mine);
         mine &= mine - 1ull;
         const int rb = lane_bcast(r, b);
         const float v = gramr_sel<KRA>(gr, rb >> 13, rb & 15);
-        if (lane == ((rb >> 4) & 63)) s_gB[b] = v;
+        if (lane == ((rb >> 4) & 63)) gb[b] = v;
       }
     }
-    if (KL > 0 && wave == 0 && want && in_lds) s_gB[lane] = g_lds[lds_index(r)];
+    if (KL > 0 && want && in_lds && my_wave) gb[lane] = g_lds[lds_index(r)];
     __syncthreads();
-    return s_gB[lane];
+    return gb[lane];
   };
 
   for (;;) {
@@ -374,25 +424,33 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     int t = 0, p0 = 0;      // sweep, first position of the batch
     float dlt = 0.0f;
     PermCtx pc = perm_make(1u, 0u);
-    // header of the NEXT batch, loaded one batch ahead (its dependent loads overlap this batch's
-    // updates): the lane's item, its x and its row record {rank | hi_k | hi2_k, hi group, nnz, |a|^2}
+    // header of the coming batches, in two stages so that no load waits for another inside a batch:
+    // stage A (two batches ahead) the lane's item from the tile's list, stage B (one batch ahead) its
+    // x and its row record {rank | hi_k | hi2_k, hi group, nnz, |a|^2}
+    int i_a = 0;
     int i_n = 0;
     uint4 m_n = make_uint4(0u, 0u, 0u, 0u);
     float xi_n = kInactive;
-    auto header = [&](const int q0) __attribute__((always_inline)) {
+    auto header_a = [&](const int q0) __attribute__((always_inline)) {
       const int pos = q0 + lane;
-      i_n = 0;
-      xi_n = kInactive;
-      if (pos < nunion) {
-        i_n = ul[perm_index(pc, (uint32_t)pos)];
-        xi_n = x[i_n];
-      }
+      i_a = pos < nunion ? ul[perm_index(pc, (uint32_t)pos)] : -1;
+    };
+    auto header_b = [&]() __attribute__((always_inline)) {
+      i_n = i_a < 0 ? 0 : i_a;
+      xi_n = i_a < 0 ? kInactive : x[i_n];
       m_n = P.meta[i_n];
     };
     int ib = 0, wpos = 0, nz = 0;  // output pass
     unsigned long long off = 0;
     bool fits = false;
     unsigned long long Uu = 0;  // SURVEY 8(d)'s U: nnz of the columns whose coefficient moved (uniform)
+#if SLIM_GRAMR_PROF
+    // (a build for scripts/gramr_prof.py only: where a problem's cycles go, reported in place of D / U / bytes / rows)
+    unsigned long long pt_fetch = 0, pt_dec = 0, pt_apply = 0, pt_first = 0, pt_mark = 0, pt_a0 = 0;
+#define SLIM_PT(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - pt_mark; pt_mark = now_; }
+#else
+#define SLIM_PT(acc)
+#endif
 
     for (;;) {  // passes
       // -- what the lanes of this pass are about
@@ -408,7 +466,8 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         mrow = m_n;
         xi = xi_n;
         part = tile_active(xi);
-        if (p0 + 64 < nunion) header(p0 + 64);
+        header_b();             // (batch p0 + 64: its items came with the previous pass)
+        header_a(p0 + 128);
         want = part;
       } else if (phase == 2) {
         i = ib + lane;
@@ -426,7 +485,11 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         r = keep ? (int)(P.meta[i].x & 0x1FFFFu) : 0;
         want = keep;
       }
+#if SLIM_GRAMR_PROF
+      pt_mark = __builtin_readcyclecounter();
+#endif
       const float g0 = fetch_g(want, r);  // (the one site that reads g out)
+      SLIM_PT(pt_fetch)
       float gi = g0;
       uint64_t pend = 0;
       if (phase == 1) {
@@ -476,10 +539,12 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
           const float d_f = lane_bcast(d, f);
           const float nx_f = lane_bcast(nx, f), xi_f = lane_bcast(xi, f);
           dlt += (nx_f - xi_f) * (nx_f - xi_f);
-          if (wave == 0 && lane == f) x[i] = nx;
+          row = lane_bcast(i, f);
+          // (addressed by the uniform `row`: a per-lane &x[i] kept for this store was spilled, and its
+          // reload put a scratch latency and a full drain in front of every update of wavefront 0)
+          if (wave == 0 && lane == f) x[row] = nx;
           pend = f == 63 ? 0ull : (pend & ~((2ull << f) - 1ull));
           if (d_f == 0.0f) continue;  // (a change below the epsilon of cd.c:27 moves no g)
-          row = lane_bcast(i, f);
           nd = -d_f;
           // (the row's record came with the batch header: no dependent load between the decision
           // and the first request of the row)
@@ -501,7 +566,7 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         const int hk = (int)((rec.x >> 17) & 15u), h2k = (int)((rec.x >> 21) & 15u);
         const uint8_t* __restrict__ plo = P.lo + (int64_t)row * P.ldb;
         const uint8_t* __restrict__ phi = P.hi + (int64_t)rec.y * kPackGroup;
-        const uint8_t* __restrict__ ph2 = P.hi2 + (h2k > 0 ? uni(P.hi2_off[row]) : 0);
+        const uint8_t* __restrict__ ph2 = phi + (int64_t)hk * kPackGroup;  // (one pool: a row's hi2 groups follow its hi groups)
         const uint8_t* __restrict__ pbase = P.base + (int64_t)row * kPackGroup;
         // a visit's lane: the entry of the row its own coordinate needs (four byte loads issued
         // together, ahead of the row; behind a plane's prefix the lane reads byte 0 and drops it)
@@ -509,6 +574,10 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         const uint32_t b0 = plo[r], b1 = phi[in1 ? r : 0], b2 = ph2[in2 ? r : 0];
         const uint32_t b3 = pbase[((r >> 4) & (NT - 1)) * 16 + (r >> 13)];
         const int rdiag = (int)(rec.x & 0x1FFFFu);
+        SLIM_PT(pt_dec)
+#if SLIM_GRAMR_PROF
+        pt_mark_v = pt_mark;
+#endif
         apply(plo, phi, ph2, pbase, hk, h2k, rdiag >> 4, rdiag & 15, __uint_as_float(rec.w), nd);  // (the one site that updates g)
         float gsel = (float)b0 + 16.0f * (float)b3;
         gsel = in1 ? fmaf(256.0f, (float)b1, gsel) : gsel;
@@ -520,6 +589,7 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
           nhi16_read += min(hk * (kPackGroup / 16), nchunks) + min(h2k * (kPackGroup / 16), nchunks);
         }
         gi = fmaf(nd, gsel, gi);
+        SLIM_PT(pt_apply)
       }
       // -- what comes next
       if (phase == 1) {
@@ -566,7 +636,9 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         p0 = 0;
         dlt = 0.0f;
         pc = perm_make((uint32_t)nunion, perm_key(S.seed, gkey, (uint32_t)t));
-        header(0);
+        header_a(0);
+        header_b();
+        header_a(64);
         continue;
       }
       // wavefront 0 counts the kept coefficients and claims the arena space
@@ -607,10 +679,17 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         S.st_na[item] = s_na;
         S.st_sweeps[item] = niters;
         S.st_conv[item] = conv;
+#if SLIM_GRAMR_PROF
+        S.st_D[item] = (int64_t)pt_fetch;
+        S.st_U[item] = (int64_t)pt_dec;
+        S.st_B[item] = (int64_t)pt_apply;
+        S.st_G[item] = (int)(pt_first_v >> 4);
+#else
         S.st_D[item] = (int64_t)s_D * (int64_t)(conv ? niters : maxit);  // (sweeps that ran)
         S.st_U[item] = (int64_t)Uu;
         S.st_G[item] = nrows_read;  // (the engine reports the staging pass's G for the column)
         S.st_B[item] = (int64_t)nrows_read * (P.ldb + 16 * (int64_t)(nchunks < NT ? nchunks : NT)) + (int64_t)nhi16_read * 16;
+#endif
         S.st_err[item] = err;
         S.st_obj[item] = err + (float)reg;
       }

@@ -889,11 +889,14 @@ bool pack_gram(slimgpu_matrix* m) {
   HIP_TRY(hipMemcpyAsync(h2k.data(), d_hi2k, sizeof(int32_t) * h2k.size(), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (hk[(size_t)ncols] != 0) return false;  // not integers in [0, 2^24): stays on the float kernels
+  // one pool: a row's hi groups, then its hi2 groups (the solver derives the second offset)
   std::vector<int64_t> off1((size_t)ncols), off2((size_t)ncols);
-  int64_t n1 = 0, n2 = 0;
+  int64_t n1 = 0, n2 = 0, npool = 0;
   for (int32_t i = 0; i < ncols; ++i) {
-    off1[(size_t)i] = n1;
-    off2[(size_t)i] = n2;
+    off1[(size_t)i] = npool;
+    npool += (int64_t)hk[(size_t)i] * kPackGroup;
+    off2[(size_t)i] = npool;
+    npool += (int64_t)h2k[(size_t)i] * kPackGroup;
     n1 += (int64_t)hk[(size_t)i] * kPackGroup;
     n2 += (int64_t)h2k[(size_t)i] * kPackGroup;
   }
@@ -902,10 +905,10 @@ bool pack_gram(slimgpu_matrix* m) {
   const size_t need = (size_t)ncols * ((size_t)ldb + kPackGroup) + (size_t)n1 + (size_t)n2 + 2 * (size_t)kPackGroup;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  if (need + (size_t(4) << 30) > free_b + m->ws_Glo.bytes + m->ws_Ghi.bytes + m->ws_Ghi2.bytes + m->ws_Gbase.bytes) return false;
+  if (need + (size_t(4) << 30) > free_b + m->ws_Glo.bytes + m->ws_Ghi.bytes + m->ws_Gbase.bytes) return false;
   uint8_t* d_lo = ws_get<uint8_t>(m->ws_Glo, (size_t)ncols * (size_t)ldb);
-  uint8_t* d_hi = ws_get<uint8_t>(m->ws_Ghi, (size_t)n1 + kPackGroup);
-  uint8_t* d_hi2 = ws_get<uint8_t>(m->ws_Ghi2, (size_t)n2 + kPackGroup);
+  uint8_t* d_hi = ws_get<uint8_t>(m->ws_Ghi, (size_t)npool + kPackGroup);
+  uint8_t* d_hi2 = d_hi;
   uint8_t* d_base = ws_get<uint8_t>(m->ws_Gbase, (size_t)ncols * kPackGroup);
   HIP_TRY(hipMemsetAsync(d_base, 0, (size_t)ncols * kPackGroup, st));
   float* d_diag = ws_get<float>(m->ws_Gdiag, (size_t)ncols);
@@ -914,8 +917,7 @@ bool pack_gram(slimgpu_matrix* m) {
   int64_t* d_off2 = ws_get<int64_t>(m->ws_hi2off, (size_t)ncols);
   HIP_TRY(hipMemcpyAsync(d_off1, off1.data(), sizeof(int64_t) * off1.size(), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_off2, off2.data(), sizeof(int64_t) * off2.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(d_hi + n1, 0, kPackGroup, st));
-  HIP_TRY(hipMemsetAsync(d_hi2 + n2, 0, kPackGroup, st));
+  HIP_TRY(hipMemsetAsync(d_hi + npool, 0, kPackGroup, st));
   hipLaunchKernelGGL(gram_pack_write_fn(), dim3(ncols), dim3(256), 0, st, dG, m->G_ld, ncols, d_item_of, nchunks,
                      d_lo, ldb, d_hi, d_off1, d_hik, d_hi2, d_off2, d_hi2k, d_base, d_diag);
   HIP_TRY(hipGetLastError());
@@ -1638,7 +1640,6 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         P.hi = static_cast<const uint8_t*>(m->ws_Ghi.p);
         P.hi_off = static_cast<const int64_t*>(m->ws_hioff.p);
         P.hi_k = static_cast<const int32_t*>(m->ws_hik.p);
-        P.hi2 = static_cast<const uint8_t*>(m->ws_Ghi2.p);
         P.hi2_off = static_cast<const int64_t*>(m->ws_hi2off.p);
         P.hi2_k = static_cast<const int32_t*>(m->ws_hi2k.p);
         P.base = static_cast<const uint8_t*>(m->ws_Gbase.p);

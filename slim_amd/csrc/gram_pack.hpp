@@ -49,9 +49,8 @@ struct GramPacked {
   const uint8_t* hi;       // pool of hi planes, row i at hi_off[i], hi_k[i] * 8192 bytes
   const int64_t* hi_off;
   const int32_t* hi_k;
-  const uint8_t* hi2;
-  const int64_t* hi2_off;
-  const int32_t* hi2_k;
+  const int64_t* hi2_off;  // bits 16-23 of the first hi2_k[i] groups: in the same pool, right behind the row's hi
+  const int32_t* hi2_k;    // groups (hi2_off[i] = hi_off[i] + hi_k[i] * 8192: the solver needs no second offset)
   const uint8_t* base;     // [ncols][8192]: byte [t * 16 + k] = b of chunk t + 512 k (0 inside the hi prefix)
   const float* diag;       // [ncols]: G_ii, kept out of the planes (see below)
   const uint4* meta;       // [ncols]: what the solver needs of a row in ONE 16-byte record, so that a lane
