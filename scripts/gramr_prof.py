@@ -19,7 +19,17 @@ def main():
     from slim_amd.engine import KERNEL_GRAM
     what = sys.argv[1] if len(sys.argv) > 1 else "c4"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-    mat = stage(what)
+    if what == "small":  # 60 000 items (the <10,3> kernel) on a matrix that solves in seconds
+        import numpy as np
+        import scipy.sparse as sp
+        from slim_amd.engine import DeviceMatrix
+        rng = np.random.default_rng(5)
+        R = sp.random(12000, 60000, density=0.002, format="csr", random_state=rng, dtype=np.float32)
+        R.data[:] = 1.0
+        R.sort_indices()
+        mat = DeviceMatrix.from_scipy(R, binary=True)
+    else:
+        mat = stage(what)
     kw = dict(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=1, kernel=KERNEL_GRAM, col_begin=0, col_end=n)
     mat.learn(**kw)
     W, st = mat.learn(**kw)

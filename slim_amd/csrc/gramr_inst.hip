@@ -21,13 +21,12 @@ GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes)
   }
   else if (k <= 6) { *kr = 6; fn = dma ? cd_gramr_kernel<6, 0, true> : cd_gramr_kernel<6, 0, false>; }
   else if (k <= 13) {
-    // <10, 3>; the ring is 4 slots deep (SLIM_GPU_GRAMR_K13=2: 3 slots -- A/B: 4.40 against 4.33 s)
-    const char* e = std::getenv("SLIM_GPU_GRAMR_K13");
-    const bool shallow = e && std::atoi(e) == 2;
+    // <10, 3>: always through the LDS ring, 4 slots (gramr_k13.hip)
     *kr = 10;
     *kl = 3;
-    ring_ah = shallow ? 2 : 3;
-    fn = gramr_kernel_k13(dma, !shallow);
+    ring_ah = 3;
+    dma = true;
+    fn = gramr_kernel_k13();
   }
   *lds_bytes = sizeof(float) * (size_t)*kl * kPackGroup + (dma ? (size_t)gramr_ring_bytes(ring_ah) : 0);
   return fn;

@@ -547,11 +547,13 @@ def _item_space_modes(monkeypatch, m, **kw):
 
 
 @pytest.mark.parametrize("shape,binary", [((40000, 3000, 0.004), False), ((30000, 15000, 0.002), False),
-                                          ((20000, 30000, 0.002), True), ((20000, 45000, 0.002), True)])
+                                          ((20000, 30000, 0.002), True), ((20000, 45000, 0.002), True),
+                                          ((12000, 60000, 0.002), True)])
 def test_packed_gram_kernels_equal_the_float_kernel_bit_for_bit(monkeypatch, shape, binary):
     """G as byte planes in popularity order (gram_pack.hpp) decodes to the very floats the unpacked
     G holds and cd_gramr.hpp applies a row with the float kernel's fmaf sequence: the models are
-    EQUAL (not close), cold and warm-started, for 1 / 3 / 6 groups of 8192 ranks, with the row
+    EQUAL (not close), cold and warm-started, for 1 / 3 / 6 / 8 groups of 8192 ranks (the last: the
+    <10,3> form, part of g in LDS), with the row
     streamed by register loads or through the LDS ring; its byte model counts fewer bytes."""
     R = _random_ratings(shape[0], shape[1], shape[2], 5)
     if binary:
