@@ -35,12 +35,13 @@ def main():
     W, st = mat.learn(**kw)
     cs = mat.column_stats()
     fetch, dec, app = float(cs.D[:n].sum()), float(cs.U[:n].sum()), float(st["gram_bytes"])
-    first = 16.0 * float(st["gram_rows"])
+    first = 256.0 * float(st["gram_rows"])
+    export = 256.0 * float(cs.nacols[:n].astype("float64").sum())
     tot = fetch + dec + app
     print("%s %d columns: kernel %.2f s; cycles of wavefront 0 over all problems: fetch %.3e (%.1f %%), decide %.3e (%.1f %%), "
-          "apply %.3e (%.1f %%) of which waiting for a row's first group %.3e (%.1f %% of all); sweeps %d"
+          "apply %.3e (%.1f %%) of which waiting for a row's first group %.3e (%.1f %% of all); of fetch, before the barrier %.3e (%.1f %% of all); sweeps %d"
           % (what, n, st["kernel_ms"] * 1e-3, fetch, 100 * fetch / tot, dec, 100 * dec / tot, app, 100 * app / tot,
-             first, 100 * first / tot, st["sweeps"]))
+             first, 100 * first / tot, export, 100 * export / tot, st["sweeps"]))
     print("   cycles per problem %.3e -> at 256 problems at a time: %.2f s at 2.4 GHz" % (tot / n, tot / 256 / 2.4e9))
 
 

@@ -99,6 +99,10 @@ __device__ __forceinline__ float gramr_sel(GramrRegs<KRA>& gr, const int k, cons
 // AH = groups requested ahead of the one consumed; the ring has AH + 1 slots of 1 KB per wavefront,
 // and one more slot takes the row's base bytes.
 constexpr int gramr_ring_bytes(int ah) { return (kGramrNT / 64) * (ah + 2) * 1024; }
+// Behind the ring, per wavefront: two buffers of 1280 bytes for the batch headers (x and the row
+// record of the 64 items of a batch), filled by LDS-DMA one batch ahead.
+constexpr int kGramrHdr = 1280;
+constexpr int gramr_hdr_bytes() { return (kGramrNT / 64) * 2 * kGramrHdr; }
 
 template <int KR, int KL, bool DMA = false, int WPS = ((KR <= 2 && KL == 0) ? 4 : 2), int AH = 2>
 __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
@@ -143,10 +147,12 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
 #define SLIM_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
   char* const ring_w = reinterpret_cast<char*>(g_lds) + KL * kPackGroup * 4 + wave * (kGramrSlots * 1024);
 #if SLIM_GRAMR_PROF
-  unsigned long long pt_first_v = 0, pt_mark_v = 0;
+  unsigned long long pt_first_v = 0, pt_mark_v = 0, pt_export_v = 0, pt_mark = 0;
   unsigned long long* const pt_first_p = &pt_first_v;
   unsigned long long* const pt_mark_p = &pt_mark_v;
 #endif
+  char* const hdr_w = reinterpret_cast<char*>(g_lds) + KL * kPackGroup * 4 + (DMA ? gramr_ring_bytes(AH) : 0) +
+                      wave * (2 * kGramrHdr);
   auto apply = [&](const uint8_t* __restrict__ plo, const uint8_t* __restrict__ phi,
                    const uint8_t* __restrict__ ph2, const uint8_t* __restrict__ pbase, const int hk,
                    const int h2k, const int cdiag, const int ediag, const float vdiag,
@@ -324,7 +330,16 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       }
     }
     if (KL > 0 && want && in_lds && my_wave) gb[lane] = g_lds[lds_index(r)];
-    __syncthreads();
+#if SLIM_GRAMR_PROF
+    pt_export_v += __builtin_readcyclecounter() - pt_mark;  // (of `fetch`: until the barrier)
+#endif
+    // (a bare barrier behind a wait for this wavefront's LDS writes: __syncthreads() adds a
+    // workgroup fence, and with the header's LDS-DMA requests in flight that fence waits for them
+    // -- a memory latency in front of every batch's barrier)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14));  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     return gb[lane];
   };
 
@@ -429,16 +444,19 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     // x and its row record {rank | hi_k | hi2_k, hi group, nnz, |a|^2}
     int i_a = 0;
     int i_n = 0;
-    uint4 m_n = make_uint4(0u, 0u, 0u, 0u);
-    float xi_n = kInactive;
+    int hw = 0;  // the header buffer the next header_b fills
     auto header_a = [&](const int q0) __attribute__((always_inline)) {
       const int pos = q0 + lane;
       i_a = pos < nunion ? ul[perm_index(pc, (uint32_t)pos)] : -1;
     };
+    // (stage B by LDS-DMA into this wavefront's header buffer: as register loads the record was
+    // spilled, and the spill put a wait for the loads just issued in front of the batch's barrier)
     auto header_b = [&]() __attribute__((always_inline)) {
       i_n = i_a < 0 ? 0 : i_a;
-      xi_n = i_a < 0 ? kInactive : x[i_n];
-      m_n = P.meta[i_n];
+      char* const hb = hdr_w + hw * kGramrHdr;
+      __builtin_amdgcn_global_load_lds(x + i_n, hb, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(P.meta + i_n, hb + 256, 16, 0, 0);
+      hw ^= 1;
     };
     int ib = 0, wpos = 0, nz = 0;  // output pass
     unsigned long long off = 0;
@@ -446,7 +464,9 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     unsigned long long Uu = 0;  // SURVEY 8(d)'s U: nnz of the columns whose coefficient moved (uniform)
 #if SLIM_GRAMR_PROF
     // (a build for scripts/gramr_prof.py only: where a problem's cycles go, reported in place of D / U / bytes / rows)
-    unsigned long long pt_fetch = 0, pt_dec = 0, pt_apply = 0, pt_first = 0, pt_mark = 0, pt_a0 = 0;
+    unsigned long long pt_fetch = 0, pt_dec = 0, pt_apply = 0;
+    pt_first_v = 0;
+    pt_export_v = 0;
 #define SLIM_PT(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - pt_mark; pt_mark = now_; }
 #else
 #define SLIM_PT(acc)
@@ -462,9 +482,20 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       uint64_t mkeep = 0;
       if (phase == 1) {
         i = i_n;
-        r = (int)(m_n.x & 0x1FFFFu);
-        mrow = m_n;
-        xi = xi_n;
+        // the header of this batch: requested one batch ago, nothing else is outstanding
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));  // vmcnt(0)
+        asm volatile("" ::: "memory");
+        {
+          const char* const hcur = hdr_w + (hw ^ 1) * kGramrHdr;
+          const bool valid = p0 + lane < nunion;
+          int lz = lane;  // (through an empty asm: hoisted out of the pass loop, lane * 4 and lane * 16 were spilled)
+          asm volatile("" : "+v"(lz));
+          const float xv = *reinterpret_cast<const float*>(hcur + lz * 4);
+          mrow = *reinterpret_cast<const uint4*>(hcur + 256 + lz * 16);
+          r = (int)(mrow.x & 0x1FFFFu);
+          xi = valid ? xv : kInactive;
+        }
+        asm volatile("" ::: "memory");
         part = tile_active(xi);
         header_b();             // (batch p0 + 64: its items came with the previous pass)
         header_a(p0 + 128);
@@ -683,7 +714,8 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         S.st_D[item] = (int64_t)pt_fetch;
         S.st_U[item] = (int64_t)pt_dec;
         S.st_B[item] = (int64_t)pt_apply;
-        S.st_G[item] = (int)(pt_first_v >> 4);
+        S.st_G[item] = (int)(pt_first_v >> 8);
+        S.st_na[item] = (int)(pt_export_v >> 8);
 #else
         S.st_D[item] = (int64_t)s_D * (int64_t)(conv ? niters : maxit);  // (sweeps that ran)
         S.st_U[item] = (int64_t)Uu;

@@ -28,7 +28,7 @@ GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes)
     dma = true;
     fn = gramr_kernel_k13();
   }
-  *lds_bytes = sizeof(float) * (size_t)*kl * kPackGroup + (dma ? (size_t)gramr_ring_bytes(ring_ah) : 0);
+  *lds_bytes = sizeof(float) * (size_t)*kl * kPackGroup + (dma ? (size_t)gramr_ring_bytes(ring_ah) : 0) + (size_t)gramr_hdr_bytes();
   return fn;
 }
 PackScanFn gram_pack_scan_fn() { return gram_pack_scan; }
