@@ -83,6 +83,9 @@ def parse_args():
                          "spread and the projected length of the driver's N-GPU command")
     ap.add_argument("--no-item-space", action="store_true",
                     help="N = 1: skip the secondary figure (first pairs of the C5 grid in item space)")
+    ap.add_argument("--shard-gram", action="store_true",
+                    help="N >= 4, the whole-matrix step in item space: form G = R^T R once by all ranks (row blocks + "
+                         "one RCCL broadcast per block, slim_amd.distributed.build_gram_sharded) instead of once per rank")
     ap.add_argument("--no-whole-matrix", action="store_true",
                     help="N >= 4: skip the extra whole-matrix (strong-scaling) step")
     ap.add_argument("--replicate", default="broadcast", choices=["broadcast", "generate"])
@@ -276,7 +279,7 @@ def main():
         dist.all_reduce(room, op=dist.ReduceOp.MIN)
         go_whole = float(room.item()) > 0.0
     if go_whole:
-        def whole(kernel, env):
+        def whole(kernel, env, shard_gram=False):
             """One step over all item columns, sharded over the ranks; never raises (a failure in an
             extra step must not cost the line its timed figures)."""
             saved = {k: os.environ.get(k) for k in env}
@@ -289,6 +292,10 @@ def main():
                 fence()
                 tw = time.perf_counter()
                 err = None
+                gram_s = None
+                if shard_gram:   # (collectives inside: opt-in, --shard-gram)
+                    from slim_amd.distributed import build_gram_sharded
+                    gram_s = build_gram_sharded(mat)
                 try:   # the solve is local to the rank: a failure here is agreed on before any collective
                     Ww, stw = mat.learn(col_begin=0, col_end=ncols, shard=(rank, world), **dict(opts, kernel=kernel))
                 except Exception as e:   # noqa: BLE001
@@ -306,7 +313,8 @@ def main():
                 return {"columns": int(ncols), "seconds": float(tw.item()),
                         "value": ncols / float(tw.item()), "unit": "item-columns/s",
                         "kernel": KERNEL_NAMES.get(stw["kernel"], stw["kernel"]),
-                        "G_build_s": round(stw["gram_build_ms"] * 1e-3, 2)}
+                        "G_build_s": round(stw["gram_build_ms"] * 1e-3, 2),
+                        "G_sharded_s": [round(x, 3) for x in gram_s] if gram_s else None}
             except Exception as e:   # noqa: BLE001
                 return {"error": "%s: %s" % (type(e).__name__, e)}
             finally:
@@ -324,7 +332,8 @@ def main():
                                 dtype=torch.float64, device=cdev)
             dist.all_reduce(room, op=dist.ReduceOp.MIN)
             if float(room.item()) > 0.0:
-                strong_whole["item_space"] = whole(5, {"SLIM_GPU_NO_GRAMCD": None, "SLIM_GPU_NO_GRAM": None})
+                strong_whole["item_space"] = whole(5, {"SLIM_GPU_NO_GRAMCD": None, "SLIM_GPU_NO_GRAM": None},
+                                                   shard_gram=args.shard_gram)
 
     if rank == 0:
         cols_total = args.steps * span
@@ -429,6 +438,15 @@ def dry_run(args, mat, ncols, per_gpu, opts, nnz):
     if not args.no_item_space:
         saved = {k: os.environ.pop(k, None) for k in ("SLIM_GPU_NO_GRAM", "SLIM_GPU_NO_GRAMCD")}
         try:
+            # (G formed once by the ranks together, --shard-gram: what rank 0's row block costs, and the commit)
+            from slim_amd.distributed import gram_blocks
+            import torch as _t
+            gb, ge = gram_blocks(ncols, N)[0]
+            _t.cuda.synchronize()
+            t0 = time.perf_counter()
+            mat.gram_build_rows(gb, ge)
+            _t.cuda.synchronize()
+            block_ms = 1e3 * (time.perf_counter() - t0)
             ir = []
             for r in range(N):
                 t0 = time.perf_counter()
@@ -441,9 +459,13 @@ def dry_run(args, mat, ncols, per_gpu, opts, nnz):
             free_b, total_b = __import__("torch").cuda.mem_get_info()
             item = {"ranks": ir, "G_build_ms_per_rank": g_ms,
                     "projected_step_s": round((g_ms + solve_ms) * 1e-3, 1),
+                    "G_row_block_build_ms": round(block_ms, 1),
+                    "projected_step_s_with_sharded_G": round((block_ms + 100.0 + 330.0 + solve_ms) * 1e-3, 1),
                     "hbm_in_use_gb_with_G": round((total_b - free_b) / 1e9, 1), "hbm_total_gb": round(total_b / 1e9, 1),
                     "note": "whole matrix in item space at N ranks: each rank pays the G build (measured once, on "
-                            "rank 0's shard) plus its shard; memory = R + G (floats + byte planes) + slabs on one GPU"}
+                            "rank 0's shard) plus its shard; memory = R + G (floats + byte planes) + slabs on one GPU; "
+                            "with_sharded_G (--shard-gram): rank 0's row block of G built alone + ~0.1 s for the N block "
+                            "broadcasts (5 GB per link at N = 8) + 0.33 s of byte planes + the shard"}
         except Exception as e:   # noqa: BLE001
             item = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:

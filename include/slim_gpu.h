@@ -165,6 +165,18 @@ int32_t SLIMGPU_MatrixGetColumnView(const slimgpu_matrix_t *mat, int64_t *colptr
  * automatic choice multiplies the columns of a call by nsolves).  0 withdraws it. */
 void SLIMGPU_MatrixExpectSolves(slimgpu_matrix_t *mat, int32_t nsolves);
 
+/* G = R^T R of item-space CD in row blocks, for drivers that run one process per GPU: every rank
+ * forms the rows of its block of items (all ncols entries of each: BuildRows), the ranks exchange
+ * their blocks into each other's buffers (View: device floats, `ld` per row -- e.g. one RCCL
+ * broadcast per block), and Commit declares every row present (and forms the byte planes where G is
+ * integer-valued).  Without these every rank builds all of G itself (what SLIMGPU_Learn does when
+ * it needs G).  No counterpart in the reference (its CD keeps the residual, src/libslim/cd.c:86-153);
+ * the sums are the a_i . a_j of estimate.c:412-421 for every pair of items.  SLIM_OK or an error
+ * code (SLIMGPU_LastError). */
+int32_t SLIMGPU_MatrixGramBuildRows(slimgpu_matrix_t *mat, int32_t row_begin, int32_t row_end);
+int32_t SLIMGPU_MatrixGramView(slimgpu_matrix_t *mat, void **dptr, int64_t *ld, int32_t *nrows);
+int32_t SLIMGPU_MatrixGramCommit(slimgpu_matrix_t *mat);
+
 /* Scheduling cost proxy per item column (the Gram work G = sum over the column's
  * users of nnz(row u)); multi-GPU drivers balance their column blocks with it. */
 int32_t SLIMGPU_MatrixColumnCost(const slimgpu_matrix_t *mat, int64_t *cost);

@@ -86,6 +86,10 @@ _SIGNATURES = {
     "SLIMGPU_MatrixGetColumnView": (C.c_int32, [C.c_void_p] * 5),
     "SLIMGPU_MatrixColumnCost": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "SLIMGPU_MatrixExpectSolves": (None, [C.c_void_p, C.c_int32]),
+    "SLIMGPU_MatrixGramBuildRows": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "SLIMGPU_MatrixGramView": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int32)]),
+    "SLIMGPU_MatrixGramCommit": (C.c_int32, [C.c_void_p]),
     "SLIMGPU_Learn": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_int32)]),
     "SLIMGPU_LearnColumns": (C.c_void_p, [C.c_void_p, C.c_int32, i32_1d, C.c_void_p, C.c_void_p,

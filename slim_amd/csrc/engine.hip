@@ -1003,6 +1003,15 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       order.swap(mine);
       nwork = (int32_t)order.size();
     }
+    // (G = R^T R by row blocks: the block's items come first in the list and only their tiles run
+    // -- a tile forms the sums with every column at or behind its own position, so the first tiles
+    // of a list form whole rows)
+    int32_t G_block = 0;
+    if (opt.build_G && opt.G_rows_end >= 0) {
+      auto in_block = [&](int32_t c) { return c >= opt.G_rows_begin && c < opt.G_rows_end; };
+      std::stable_partition(order.begin(), order.end(), in_block);
+      G_block = (int32_t)std::count_if(order.begin(), order.end(), in_block);
+    }
     const std::vector<int32_t> requested = order;
 
     // kernel flavour and geometry
@@ -1520,6 +1529,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       S.ulist = d_ulist;
       S.u_stride = (int64_t)tile_u;
       S.ngroups = (npend + tileP - 1) / tileP;
+      if (opt.build_G && opt.G_rows_end >= 0) S.ngroups = (G_block + tileP - 1) / tileP;
       S.cluster = clusterK;
       S.ubounds = use_tile ? m->d_ubounds[cluster_lg] : nullptr;
       S.csplit = use_tile ? m->d_csplit[cluster_lg] : nullptr;
@@ -1926,6 +1936,80 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
   } catch (const std::bad_alloc&) {
     set_error("SLIMGPU_Learn: out of host memory");
     return fail(SLIM_ERROR_MEMORY);
+  }
+}
+
+// -- G = R^T R in row blocks (engine.hpp) ---------------------------------------------------
+int32_t gram_build_rows(slimgpu_matrix_t* m, int32_t row_begin, int32_t row_end) {
+  if (!m || row_begin < 0 || row_end > m->ncols || row_begin > row_end) {
+    set_error("SLIMGPU_MatrixGramBuildRows: rows outside [0, ncols)");
+    return SLIM_ERROR_INPUT;
+  }
+  try {
+    HIP_TRY(hipSetDevice(m->device));
+    const int32_t ncols = m->ncols;
+    const int64_t G_ld = round_up(round_up(ncols, 64), 64);
+    const size_t G_bytes = sizeof(float) * (size_t)ncols * (size_t)G_ld;
+    if (m->G_ready || m->ws_G.bytes < G_bytes) {  // a fresh G: nothing of an earlier one is kept
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+      if (G_bytes + (size_t(8) << 30) > free_b + m->ws_G.bytes + m->ws_gram.bytes) {
+        set_error("SLIMGPU_MatrixGramBuildRows: G = R^T R (4 ncols^2 bytes) does not fit the free HBM");
+        return SLIM_ERROR_MEMORY;
+      }
+      drop_screen_cache(m);
+      float* dG = ws_get<float>(m->ws_G, (size_t)ncols * (size_t)G_ld);
+      HIP_TRY(hipMemsetAsync(dG, 0, G_bytes, m->stream));
+      m->G_ld = G_ld;
+      m->G_ready = false;
+      m->Gp_ready = false;
+      m->Gp_tried = false;
+    }
+    if (row_begin == row_end) return SLIM_OK;
+    LearnOptions bo;
+    bo.kernel = SLIMGPU_KERNEL_TILE;
+    bo.build_G = true;
+    bo.G_rows_begin = row_begin;
+    bo.G_rows_end = row_end;
+    bo.heavy_tiles = 0;
+    int32_t bst = SLIM_OK;
+    slim_csr_t* none = learn_cd(m, bo, nullptr, &bst, nullptr, 0, false);
+    if (!none) return bst;
+    csr_free(none);
+    return SLIM_OK;
+  } catch (const HipError& e) {
+    report(e, "SLIMGPU_MatrixGramBuildRows");
+    return status_of(e);
+  }
+}
+
+int32_t gram_view(slimgpu_matrix_t* m, void** dptr, int64_t* ld, int32_t* nrows) {
+  if (!m || !m->ws_G.p || m->G_ld <= 0) {
+    set_error("SLIMGPU_MatrixGramView: no G on this handle (SLIMGPU_MatrixGramBuildRows first)");
+    return SLIM_ERROR_INPUT;
+  }
+  if (dptr) *dptr = m->ws_G.p;
+  if (ld) *ld = m->G_ld;
+  if (nrows) *nrows = m->ncols;
+  return SLIM_OK;
+}
+
+int32_t gram_commit(slimgpu_matrix_t* m) {
+  if (!m || !m->ws_G.p || m->G_ld <= 0) {
+    set_error("SLIMGPU_MatrixGramCommit: no G on this handle");
+    return SLIM_ERROR_INPUT;
+  }
+  try {
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->G_ready = true;
+    m->Gp_ready = false;
+    m->Gp_tried = false;
+    (void)pack_gram(m);  // (false: G is not integer-valued or the planes do not fit -- float kernels)
+    return SLIM_OK;
+  } catch (const HipError& e) {
+    report(e, "SLIMGPU_MatrixGramCommit");
+    return status_of(e);
   }
 }
 

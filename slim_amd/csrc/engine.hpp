@@ -23,6 +23,7 @@ struct LearnOptions {
   int32_t ngpus = 1;          // SLIM_Learn & co: devices to shard over (multi_gpu.cpp)
   int32_t shard_count = 1, shard_index = 0;  // one shard of the cost-ordered work list
   bool build_G = false;  // internal: this call fills G = R^T R (engine.hip), it solves nothing
+  int32_t G_rows_begin = 0, G_rows_end = -1;  // internal, with build_G: only rows [begin, end) of G (-1: all)
 };
 LearnOptions decode_options(const int32_t* ioptions, const double* doptions);
 
@@ -55,6 +56,14 @@ int32_t matrix_column_cost(const slimgpu_matrix_t* m, int64_t* cost);
 // the caller is about to solve this matrix n times (a model-selection grid): lets the engine pay
 // for G = R^T R up front (item-space CD, cd_gram.hpp)
 void matrix_expect_solves(slimgpu_matrix_t* m, int32_t n);
+// G = R^T R in pieces (multi-GPU: every rank forms the rows of a block of items, the blocks are
+// exchanged by the caller, e.g. an RCCL broadcast per block into the view below, then committed):
+// gram_build_rows fills rows [row_begin, row_end) of the handle's G (all of its ncols entries each),
+// gram_view gives the device buffer (floats, ld per row), gram_commit declares every row present and
+// forms the byte planes.  SLIM_OK or an error code (set_error).
+int32_t gram_build_rows(slimgpu_matrix_t* m, int32_t row_begin, int32_t row_end);
+int32_t gram_view(slimgpu_matrix_t* m, void** dptr, int64_t* ld, int32_t* nrows);
+int32_t gram_commit(slimgpu_matrix_t* m);
 
 // EstimateModelCD + SaveModel on the device matrix.  Returns a host model
 // (slim_csr_t with both views) or nullptr with *status set.

@@ -408,6 +408,21 @@ void SLIMGPU_MatrixExpectSolves(slimgpu_matrix_t* mat, int32_t nsolves) {
   matrix_expect_solves(mat, nsolves);
 }
 
+int32_t SLIMGPU_MatrixGramBuildRows(slimgpu_matrix_t* mat, int32_t row_begin, int32_t row_end) {
+  set_error("");
+  return gram_build_rows(mat, row_begin, row_end);
+}
+
+int32_t SLIMGPU_MatrixGramView(slimgpu_matrix_t* mat, void** dptr, int64_t* ld, int32_t* nrows) {
+  set_error("");
+  return gram_view(mat, dptr, ld, nrows);
+}
+
+int32_t SLIMGPU_MatrixGramCommit(slimgpu_matrix_t* mat) {
+  set_error("");
+  return gram_commit(mat);
+}
+
 slim_t* SLIMGPU_Learn(slimgpu_matrix_t* mat, int32_t* ioptions, double* doptions, slim_t* imodel,
                       int32_t* r_status) {
   set_error("");

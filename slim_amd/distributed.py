@@ -113,6 +113,51 @@ def gather_model(W_local, group=None, dst=None):
     return sp.csc_matrix((data, indices, indptr), shape=(n, n))
 
 
+def gram_blocks(ncols, world_size):
+    """Contiguous, equal (to one row) blocks of item ids, one per rank."""
+    per = (ncols + world_size - 1) // world_size
+    return [(min(r * per, ncols), min((r + 1) * per, ncols)) for r in range(world_size)]
+
+
+def build_gram_sharded(mat, group=None):
+    """G = R^T R of a replicated DeviceMatrix, formed ONCE by the ranks together instead of once
+    per rank: rank r forms the rows of block r (SLIMGPU_MatrixGramBuildRows), every block is
+    broadcast from its owner straight into the other ranks' buffers (one RCCL broadcast per block:
+    blocks may differ by a row, and 5 GB per link is ~50 ms on xGMI), then every rank commits
+    (byte planes are formed locally).  Returns the seconds spent (build, exchange, commit).
+    With one rank this is the plain build."""
+    import time
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    blocks = gram_blocks(mat.ncols, world)
+    t0 = time.perf_counter()
+    b, e = blocks[rank]
+    mat.gram_build_rows(b, e)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if world > 1:
+        on_device = dist.get_backend(group) == "nccl"   # (gloo: ranks sharing a device in the tests -- host bounce)
+        for r, (rb, re) in enumerate(blocks):
+            if re <= rb:
+                continue
+            src = dist.get_global_rank(group, r) if group else r
+            block = mat.gram_rows_tensor(rb, re)
+            if on_device:
+                dist.broadcast(block, src=src, group=group)
+            else:
+                host = block.cpu() if r == rank else torch.empty(block.shape, dtype=block.dtype)
+                dist.broadcast(host, src=src, group=group)
+                if r != rank:
+                    block.copy_(host)
+        torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    mat.gram_commit()
+    t3 = time.perf_counter()
+    return t1 - t0, t2 - t1, t3 - t2
+
+
 STAT_KEYS = ("objval", "error", "nnzW", "G", "D", "U", "sweeps", "ncols_solved")
 
 

@@ -189,6 +189,41 @@ class DeviceMatrix(object):
         and solve in item space (SLIMGPU_MatrixExpectSolves)."""
         self._lib.SLIMGPU_MatrixExpectSolves(self.handle, int(n))
 
+    # -- G = R^T R of item-space CD in row blocks (slim_gpu.h; slim_amd.distributed.build_gram_sharded)
+    def gram_build_rows(self, row_begin, row_end):
+        """Form rows [row_begin, row_end) of G on this handle (every entry of each)."""
+        st = self._lib.SLIMGPU_MatrixGramBuildRows(self.handle, int(row_begin), int(row_end))
+        if st != SLIM_OK:
+            raise RuntimeError("SLIMGPU_MatrixGramBuildRows failed (%d): %s" % (st, _lib.last_error()))
+
+    def gram_view(self):
+        """(device pointer, floats per row, rows) of the handle's G."""
+        p, ld, n = C.c_void_p(), C.c_int64(), C.c_int32()
+        st = self._lib.SLIMGPU_MatrixGramView(self.handle, C.byref(p), C.byref(ld), C.byref(n))
+        if st != SLIM_OK:
+            raise RuntimeError("SLIMGPU_MatrixGramView failed (%d): %s" % (st, _lib.last_error()))
+        return p.value, ld.value, n.value
+
+    def gram_rows_tensor(self, row_begin, row_end):
+        """Rows [row_begin, row_end) of G as a torch tensor that ALIASES the engine's buffer
+        (a contiguous (rows, ld) float32 block on this handle's device)."""
+        import torch
+        ptr, ld, n = self.gram_view()
+
+        class _Alias:
+            pass
+        a = _Alias()
+        a.__cuda_array_interface__ = {
+            "shape": (int(row_end - row_begin), int(ld)), "typestr": "<f4",
+            "data": (int(ptr) + 4 * int(ld) * int(row_begin), False), "version": 2, "strides": None}
+        return torch.as_tensor(a, device="cuda")
+
+    def gram_commit(self):
+        """Every row of G is in place: item-space solves may use it (byte planes are formed)."""
+        st = self._lib.SLIMGPU_MatrixGramCommit(self.handle)
+        if st != SLIM_OK:
+            raise RuntimeError("SLIMGPU_MatrixGramCommit failed (%d): %s" % (st, _lib.last_error()))
+
 
 def _scipy_to_model_handle(lib, W):
     """Model handle (row + column views) from a scipy matrix, via the text-free

@@ -1318,3 +1318,41 @@ def test_admm_matches_oracle(ml100k, automotive, capfd):
     model.train({"algo": "admm", "l1r": 1.0, "l2r": 1.0}, trn)
     out = model.predict(trn, nrcmds=5)
     assert len(out) > 0
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_gram_in_row_blocks_equals_the_whole_build(binary):
+    """G = R^T R formed in row blocks on two handles ("ranks"), exchanged block by block into each
+    other's buffers and committed (SLIMGPU_MatrixGramBuildRows / View / Commit: what
+    slim_amd.distributed.build_gram_sharded does over RCCL) is the G a handle builds for itself,
+    entry for entry, and the item-space models are equal."""
+    import torch
+    from slim_amd.distributed import build_gram_sharded, gram_blocks
+    R = _random_ratings(20000, 6000, 0.004, 7)
+    if binary:
+        R.data[:] = 1.0
+    whole = DeviceMatrix.from_scipy(R, binary=binary)
+    W0, s0 = whole.learn(kernel=KERNEL_GRAM, seed=2)
+    assert s0["gram_build_ms"] > 0
+    ranks = [DeviceMatrix.from_scipy(R, binary=binary) for _ in range(2)]
+    blocks = gram_blocks(whole.ncols, 2)
+    assert blocks == [(0, 3000), (3000, 6000)]
+    for m, (b, e) in zip(ranks, blocks):
+        m.gram_build_rows(b, e)
+    torch.cuda.synchronize()
+    for r, (b, e) in enumerate(blocks):          # "broadcast" block r from its owner
+        ranks[1 - r].gram_rows_tensor(b, e).copy_(ranks[r].gram_rows_tensor(b, e))
+    torch.cuda.synchronize()
+    G0 = whole.gram_rows_tensor(0, whole.ncols)[:, :whole.ncols]
+    for m in ranks:
+        m.gram_commit()
+        assert torch.equal(m.gram_rows_tensor(0, m.ncols)[:, :m.ncols], G0)
+        W, s = m.learn(kernel=KERNEL_GRAM, seed=2)
+        assert s["gram_build_ms"] == 0 and maxdiff(W, W0) == 0.0
+        m.close()
+    # one rank: the helper is the plain build
+    one = DeviceMatrix.from_scipy(R, binary=binary)
+    build_gram_sharded(one)
+    assert torch.equal(one.gram_rows_tensor(0, one.ncols)[:, :one.ncols], G0)
+    one.close()
+    whole.close()

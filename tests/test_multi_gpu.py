@@ -325,6 +325,16 @@ def _rank_worker(rank, world, port, out_dir):
             sp.save_npz(os.path.join(out_dir, "%s%d.npz" % (partition, rank)), sp.csc_matrix(W))
             np.save(os.path.join(out_dir, "%s%d.npy" % (partition, rank)),
                     np.array([stats["totals"]["ncols_solved"], stats["totals"]["nnzW"]]))
+        # G = R^T R formed once by the ranks together (row blocks, one broadcast per block), then the
+        # sharded solve in item space on it
+        from slim_amd.distributed import build_gram_sharded
+        from slim_amd.engine import KERNEL_GRAM
+        build_gram_sharded(mat)
+        G = mat.gram_rows_tensor(0, mat.ncols)[:, :mat.ncols].cpu().numpy()
+        np.save(os.path.join(out_dir, "G%d.npy" % rank), G)
+        W, stats, _ = learn_sharded(mat, seed=1, kernel=KERNEL_GRAM)
+        assert stats["gram_build_ms"] == 0
+        sp.save_npz(os.path.join(out_dir, "gram%d.npz" % rank), sp.csc_matrix(W))
         mat.close()
     finally:
         dist.destroy_process_group()
@@ -351,6 +361,15 @@ def test_one_process_per_gpu_driver_on_device(ml100k, tmp_path):
         assert abs(w0 - w1).nnz == 0 and maxdiff(w0, want) == 0.0 and w0.nnz == want.nnz
         t = np.load(str(tmp_path / (partition + "0.npy")))
         assert t[0] == R.shape[1] and t[1] == want.nnz
+    # G formed by the two ranks together is R^T R on both, and the item-space model on it is the
+    # single-GPU item-space model
+    m = DeviceMatrix.from_scipy(R)
+    want_g, _ = m.learn(seed=1, kernel=5)
+    m.close()
+    G = (R.T @ R).toarray().astype(np.float32)
+    for rank in (0, 1):
+        assert np.array_equal(np.load(str(tmp_path / ("G%d.npy" % rank))), G)
+        assert maxdiff(sp.load_npz(str(tmp_path / ("gram%d.npz" % rank))), want_g) == 0.0
 
 
 @pytest.mark.timeout(420, method="thread")
