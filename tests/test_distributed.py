@@ -27,6 +27,20 @@ def test_partition_columns_balances_cost():
     assert partition_columns([], 2) == [(0, 0), (0, 0)]
 
 
+def test_gram_blocks_cover_the_items_once():
+    """Row blocks of G = R^T R for N ranks (build_gram_sharded): contiguous, in order, equal to one row,
+    empty blocks only behind the last item."""
+    from slim_amd.distributed import gram_blocks
+    for ncols, world in ((100000, 8), (20000, 8), (1683, 4), (5, 8), (0, 2), (7, 1)):
+        blocks = gram_blocks(ncols, world)
+        assert len(blocks) == world and blocks[0][0] == 0 and blocks[-1][1] == ncols
+        assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+        sizes = [e - b for b, e in blocks]
+        assert all(s >= 0 for s in sizes) and sum(sizes) == ncols
+        nonempty = [s for s in sizes if s > 0]
+        assert sizes == sorted(sizes, reverse=True)      # full blocks first, then a shorter one, then empty ones
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
