@@ -424,8 +424,8 @@ def test_bench_plain_command_launches_its_own_ranks():
 def test_bench_four_ranks_whole_matrix_extras():
     """The N >= 4 branch of bench.py as the driver will run it at N = 4 / 8, on a 1/50-scale C4
     (20 000 x 2 000): after the timed steps one step over ALL item columns sharded over the ranks
-    (`strong_whole_matrix`) and the same step in item space (`item_space`: every rank builds
-    G = R^T R, then solves its shard) -- both agreed on by all ranks before any collective, so a
+    (`strong_whole_matrix`) and the same step in item space (`item_space`: G = R^T R formed in row
+    blocks by the ranks together, --shard-gram, then every rank solves its shard) -- both agreed on by all ranks before any collective, so a
     failure in an extra step costs its key, not the line.  On a one-GPU box the four ranks share
     the device over gloo (clusters of 1: co-residency across processes is not a given there)."""
     import json
@@ -435,7 +435,7 @@ def test_bench_four_ranks_whole_matrix_extras():
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1",
            "--workload", "c4", "--scale", "0.02", "--batch", "256", "--cluster", "1",
-           "--backend", backend, "--cpu-seconds", "0"]
+           "--backend", backend, "--cpu-seconds", "0", "--shard-gram"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -443,6 +443,9 @@ def test_bench_four_ranks_whole_matrix_extras():
     sw = out["strong_whole_matrix"]
     assert sw["columns"] == 2000 and sw["seconds"] > 0 and sw["kernel"] == "tile32", sw
     assert sw["item_space"]["kernel"] == "gram" and sw["item_space"]["seconds"] > 0, sw
+    # --shard-gram: G was formed once by the four ranks together (row blocks, one broadcast per
+    # block), so the solve itself built nothing
+    assert len(sw["item_space"]["G_sharded_s"]) == 3 and sw["item_space"]["G_build_s"] == 0, sw
 
 
 @pytest.mark.timeout(600, method="thread")
@@ -464,3 +467,5 @@ def test_bench_dry_run_of_an_eight_rank_step():
     # nothing; at full size it is 1.3 %, profiles/r04/dry_run_world8.json)
     assert out["kernel_ms_spread"] >= 0.0 and out["kernel_ms_mean"] > 0
     assert out["projected_command_s"]["total"] > 0
+    item = out["item_space_whole_matrix"]
+    assert item["G_row_block_build_ms"] > 0 and item["projected_step_s_with_sharded_G"] > 0, item
