@@ -75,21 +75,24 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// entry e of group k for wave-uniform k, e
+// entry e of group k for wave-uniform k, e: a chain of uniform branches down to the group, then one
+// register-indirect move.  (The group is also an input of an empty asm: a vector with a single use
+// -- "load the group, take element e" -- is folded into a scalar load at a variable address and the
+// whole struct stays in memory; with a second use it is the group's registers that are indexed.  The
+// first form of this, an in-out operand, cost a copy of the 16 registers per read.)
+template <int N, int KRA>
+__device__ __forceinline__ float gramr_sel_from(GramrRegs<KRA>& gr, const int k, const int e) {
+  if (k == N) {
+    const gramr_v16 t = gramr_reg<N>(gr);
+    asm volatile("" ::"v"(t));
+    return t[e];
+  }
+  if constexpr (N + 1 < KRA) return gramr_sel_from<N + 1, KRA>(gr, k, e);
+  return 0.0f;
+}
 template <int KRA>
 __device__ __forceinline__ float gramr_sel(GramrRegs<KRA>& gr, const int k, const int e) {
-  float v = 0.0f;
-  static_for<KRA>([&](auto kc) __attribute__((always_inline)) {
-    constexpr int n = decltype(kc)::value;
-    if (k == n) {
-      // (the copy goes through an empty asm: otherwise the optimizer folds "load the group, take
-      // element e" into one scalar load at a variable address and the whole struct stays in memory)
-      gramr_v16 t = gramr_reg<n>(gr);
-      asm volatile("" : "+v"(t));
-      v = t[e];
-    }
-  });
-  return v;
+  return gramr_sel_from<0, KRA>(gr, k, e);
 }
 
 // KR groups of 8192 ranks in registers, KL groups in LDS (dynamic: KL * 32 KB).
