@@ -656,7 +656,8 @@ def ml100k_parity(device):
 
 KERNEL_SOURCES = ("cd_tile.hpp", "cd_wave.hpp", "cd_perm.hpp", "engine.hip", "tile_inst.hpp")
 # the item-space path on top of those (its launches, G builder and kernels)
-GRAM_SOURCES = ("cd_gram.hpp", "cd_gramr.hpp", "gram_pack.hpp", "gram_inst.hpp")
+GRAM_SOURCES = ("cd_gram.hpp", "cd_gramr.hpp", "gram_pack.hpp", "gram_inst.hpp", "gram_inst.hip",
+                "gramr_inst.hpp", "gramr_inst.hip", "gramr_k13.hip")   # (the last three choose the instantiation)
 
 
 def kernel_hash(kind="tile"):
@@ -668,8 +669,7 @@ def kernel_hash(kind="tile"):
     names = KERNEL_SOURCES + (GRAM_SOURCES if kind == "gram" else ())
     for name in names:
         path = os.path.join(ROOT, "slim_amd", "csrc", name)
-        if not os.path.exists(path):
-            continue
+        h.update(name.encode())     # (a renamed or missing source must not match an old entry)
         with open(path) as f:
             text = f.read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # comments and layout do not

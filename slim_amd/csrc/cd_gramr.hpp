@@ -43,6 +43,13 @@
 #ifndef SLIM_GRAMR_PROF
 #define SLIM_GRAMR_PROF 0
 #endif
+// bisect switches of scripts/gramr_k13_sweep.py (A/B builds only; all 0 in the product):
+#ifndef SLIM_GRAMR_DRAIN     // every ring wait drains everything outstanding
+#define SLIM_GRAMR_DRAIN 0
+#endif
+#ifndef SLIM_GRAMR_SYNCROW   // a workgroup barrier behind every row
+#define SLIM_GRAMR_SYNCROW 0
+#endif
 
 namespace slimamd {
 
@@ -147,7 +154,11 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
   const uint32_t voff0 = 16u * (uint32_t)tid;
   const uint32_t vlast = 16u * (uint32_t)(nchunks - 1);
   // s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+#if SLIM_GRAMR_DRAIN
+#define SLIM_VMCNT(n) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8))
+#else
 #define SLIM_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
+#endif
   char* const ring_w = reinterpret_cast<char*>(g_lds) + KL * kPackGroup * 4 + wave * (kGramrSlots * 1024);
 #if SLIM_GRAMR_PROF
   unsigned long long pt_first_v = 0, pt_mark_v = 0, pt_export_v = 0, pt_mark = 0;
@@ -623,6 +634,9 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
           nhi16_read += min(hk * (kPackGroup / 16), nchunks) + min(h2k * (kPackGroup / 16), nchunks);
         }
         gi = fmaf(nd, gsel, gi);
+#if SLIM_GRAMR_SYNCROW
+        __syncthreads();
+#endif
         SLIM_PT(pt_apply)
       }
       // -- what comes next

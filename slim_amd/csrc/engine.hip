@@ -863,6 +863,13 @@ bool pack_gram(slimgpu_matrix* m) {
   std::vector<int64_t> cp((size_t)ncols + 1);
   HIP_TRY(hipMemcpy(cp.data(), m->d_colptr, sizeof(int64_t) * cp.size(), hipMemcpyDeviceToHost));
   const int32_t nchunks = (ncols + 15) / 16;
+  // Nothing reads the planes beyond the largest on-chip instantiation (gramr_kernel(): 13 groups of
+  // 8192 ranks = 106 496 items), and their layout ends not far behind it: one base byte per group in
+  // a 16-byte record per thread (16 groups), 17 bits of rank and 4 bits of hi_k / hi2_k in the row
+  // record (131 072 ranks, 15 groups).  Larger matrices stay on the float kernels.
+  static_assert(kGramrMaxGroups <= 15 && kGramrMaxGroups * kPackGroup <= (1 << 17),
+                "row record: 17 bits of rank, 4 bits per plane length; base bytes: 16 groups per thread");
+  if ((nchunks + kGramrNT - 1) / kGramrNT > kGramrMaxGroups) return false;
   std::vector<int32_t> item_of((size_t)nchunks * 16, -1), rank_of((size_t)ncols);
   std::iota(item_of.begin(), item_of.begin() + ncols, 0);
   std::stable_sort(item_of.begin(), item_of.begin() + ncols, [&](int32_t a, int32_t b) {

@@ -13,7 +13,7 @@ using GramrFn = void (*)(const DevMatrix, const SolveArgs, const GramPacked);
 // dma: the variant that streams rows through an LDS ring (global_load_lds); lds_bytes = the dynamic
 // LDS the chosen instantiation needs
 GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes);
-GramrFn gramr_kernel_k13();  // <10, 3, ring>: its own translation unit (compiles beside the others)
+GramrFn gramr_kernel_k13(bool* dma, int* ring_ah);  // <10, 3>: its own translation unit (compiles beside the others)
 
 using PackScanFn = void (*)(const float*, int64_t, int, const int32_t*, int, int, int32_t*, int32_t*, int32_t*);
 using PackWriteFn = void (*)(const float*, int64_t, int, const int32_t*, int, uint8_t*, int64_t, uint8_t*,

@@ -134,11 +134,26 @@ def build_gram_sharded(mat, group=None):
     blocks = gram_blocks(mat.ncols, world)
     t0 = time.perf_counter()
     b, e = blocks[rank]
-    mat.gram_build_rows(b, e)
-    torch.cuda.synchronize()
+    # A rank whose own block fails (out of memory, say) must not leave the others waiting in a
+    # broadcast: the ranks agree on the outcome BEFORE the first collective on G and raise together.
+    err = None
+    try:
+        mat.gram_build_rows(b, e)
+        torch.cuda.synchronize()
+    except Exception as ex:  # noqa: BLE001 (reported to every rank below)
+        err = ex
     t1 = time.perf_counter()
     if world > 1:
         on_device = dist.get_backend(group) == "nccl"   # (gloo: ranks sharing a device in the tests -- host bounce)
+        bad = torch.tensor([0 if err is None else 1], dtype=torch.int32,
+                           device=torch.device("cuda", mat.device) if on_device else "cpu")
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=group)
+        if int(bad.item()):
+            raise RuntimeError("build_gram_sharded: %d rank(s) could not form their block of G%s"
+                               % (int(bad.item()), "" if err is None else " (this rank: %s)" % err))
+    elif err is not None:
+        raise err
+    if world > 1:
         for r, (rb, re) in enumerate(blocks):
             if re <= rb:
                 continue

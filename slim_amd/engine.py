@@ -209,6 +209,8 @@ class DeviceMatrix(object):
         (a contiguous (rows, ld) float32 block on this handle's device)."""
         import torch
         ptr, ld, n = self.gram_view()
+        if not 0 <= row_begin <= row_end <= n:
+            raise ValueError("gram_rows_tensor: rows [%d, %d) outside [0, %d)" % (row_begin, row_end, n))
 
         class _Alias:
             pass
@@ -216,7 +218,12 @@ class DeviceMatrix(object):
         a.__cuda_array_interface__ = {
             "shape": (int(row_end - row_begin), int(ld)), "typestr": "<f4",
             "data": (int(ptr) + 4 * int(ld) * int(row_begin), False), "version": 2, "strides": None}
-        return torch.as_tensor(a, device="cuda")
+        # (on the handle's device, not the current one: a copy instead of an alias would swallow
+        # the broadcast of build_gram_sharded and commit a G with missing rows)
+        t = torch.as_tensor(a, device=torch.device("cuda", self.device))
+        if t.numel() and t.data_ptr() != a.__cuda_array_interface__["data"][0]:
+            raise RuntimeError("gram_rows_tensor: torch copied the block instead of aliasing it")
+        return t
 
     def gram_commit(self):
         """Every row of G is in place: item-space solves may use it (byte planes are formed)."""

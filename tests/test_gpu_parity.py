@@ -576,6 +576,58 @@ def test_packed_gram_kernels_equal_the_float_kernel_bit_for_bit(monkeypatch, sha
     m.close()
 
 
+def test_item_space_100k_items_the_lds_groups_of_g(monkeypatch):
+    """cd_gramr_kernel<10,3> with all thirteen groups of g alive: 100 000 items, every rank as likely a
+    coefficient as any other (uniform popularity), so the visits read and the rows update the three
+    LDS groups (ranks >= 81 920) as much as the ten register groups -- below full size (the 1M x 100K
+    test is the only other place they hold live coordinates).  Whole matrix: models EQUAL to the
+    float item-space kernel's, cold and warm-started; 128 columns (the most and the least popular)
+    against the oracle's tile walk (cd.c:112-139 in the tile's visiting order) <= 2e-5, same active
+    sets, same sweeps."""
+    nu, ni = 4000, 100000
+    rng = np.random.default_rng(11)
+    R = sp.random(nu, ni, density=0.005, format="csr", random_state=rng, dtype=np.float32)
+    R.data[:] = 1.0
+    R.sort_indices()
+    m = DeviceMatrix.from_scipy(R, binary=True)
+    kw = dict(seed=3, l1r=0.5, l2r=1.0)
+    monkeypatch.setenv("SLIM_GPU_NO_GRAMR", "1")
+    Wf, sf = m.learn(kernel=KERNEL_GRAM, **kw)
+    cf = m.column_stats()
+    monkeypatch.delenv("SLIM_GPU_NO_GRAMR")
+    Wp, sp_ = m.learn(kernel=KERNEL_GRAM, **kw)
+    cp = m.column_stats()
+    assert sp_["kernel"] == KERNEL_GRAM and 0 < sp_["gram_bytes"] < 0.5 * sf["gram_bytes"]   # (the packed kernel ran)
+    assert Wf.nnz > 1000000 and maxdiff(Wf, Wp) == 0.0
+    assert np.array_equal(cf.sweeps, cp.sweeps) and np.array_equal(cf.U, cp.U)
+    # coefficients sit on the LDS ranks too
+    nnzc = np.diff(R.tocsc().indptr)
+    rank = np.empty(ni, np.int64)
+    rank[np.lexsort((np.arange(ni), -nnzc))] = np.arange(ni)
+    assert (rank[Wp.tocoo().row] >= 81920).mean() > 0.1
+    # warm start from another model (estimate.c:453-464)
+    monkeypatch.setenv("SLIM_GPU_NO_GRAMR", "1")
+    Wf2, _ = m.learn(kernel=KERNEL_GRAM, imodel=Wf, **dict(kw, l2r=3.0))
+    cf2 = m.column_stats()
+    monkeypatch.delenv("SLIM_GPU_NO_GRAMR")
+    Wp2, _ = m.learn(kernel=KERNEL_GRAM, imodel=Wf, **dict(kw, l2r=3.0))
+    cp2 = m.column_stats()
+    assert maxdiff(Wf2, Wp2) == 0.0 and np.array_equal(cf2.sweeps, cp2.sweeps)
+    # four tiles against the oracle: the 64 most and the 64 least popular items
+    cost = m.column_cost()
+    by_pop = np.argsort(-nnzc, kind="stable")
+    cols = np.concatenate([by_pop[:64], by_pop[-64:]]).astype(np.int32)
+    order = cols[np.argsort(-cost[cols], kind="stable")]
+    Wg, sg = m.learn(kernel=KERNEL_GRAM, columns=cols, **kw)
+    cg = m.column_stats()
+    Wo, so, _, _ = O.learn_cd_tile(R, tileP=32, order=order, nthreads=8, binary=True, return_stats=True, **kw)
+    assert Wg[:, cols].nnz > 1000 and maxdiff(Wg[:, cols], Wo[:, cols]) <= 2e-5
+    assert maxdiff(Wg[:, cols], Wp[:, cols]) <= 2e-5     # (another tile grouping: another visiting order)
+    assert np.array_equal(cg.nacols[cols], so["nacols"][cols])
+    assert (cg.sweeps[cols] == so["sweeps"][cols]).mean() >= 0.98
+    m.close()
+
+
 def test_packed_gram_third_plane_and_the_float_fallback(monkeypatch):
     """Co-rating counts beyond 65 535 take the third byte plane (70 000 users rate items 0-2: G
     entries of 70 000), still bit-equal to the float kernel and within tolerance of the oracle's tile
