@@ -102,6 +102,86 @@ __device__ __forceinline__ float gramr_sel(GramrRegs<KRA>& gr, const int k, cons
   return gramr_sel_from<0, KRA>(gr, k, e);
 }
 
+// The export of a batch in ONE loop of 14 instructions per entry, written by hand (round 6).  The
+// compiler's form of `gramr_sel` above is a tree of uniform branches down to the group (the
+// register-indirect move needs a static base register) plus a lane-masked LDS write per entry: ~40
+// instructions with ten branches, 388 cycles per entry at two wavefronts per SIMD
+// (profiles/r05/gramr_cycle_profile_c4.txt) -- a quarter of the kernel's cycles with the barrier
+// that waits for the slowest wavefront's export.  Here every group is an input operand PINNED to
+// fixed registers (group k in v[16 + 16 k : 31 + 16 k]: the allocator keeps the groups there for
+// the whole kernel, the ISA is checked for copies by scripts/isa_metadata.sh), so entry (k, e) is
+// v[16 + 16 k + e] = ONE indexed move with no branch; the value goes from its owner's lane to an
+// SGPR (v_readlane) and from there into lane b of a result register (a move under EXEC = 1 << b:
+// v_writelane with an SGPR value AND an SGPR lane select breaks gfx9's one-scalar-operand rule) --
+// no branch and no LDS access inside the loop; the caller stores the result register once.
+//   mine: the lanes (visits) whose coordinate this wavefront holds in registers; r: the lanes' ranks.
+// Wait states (gfx9 ISA, "manually inserted wait states": the assembler adds none inside an asm
+// block): the lane selects of both v_readlane are written by SALU instructions (s_ff1, s_bfe), not by
+// a VALU -- no wait states; the SGPR written by v_readlane is read by SALU instructions and as a
+// VALU source operand (v_writelane's data), both interlocked; M0 is saved and restored around the
+// loop (s_set_gpr_idx_on writes it).
+#ifndef SLIM_GRAMR_ASMEXPORT
+#define SLIM_GRAMR_ASMEXPORT 1
+#endif
+#define SLIM_GRAMR_EXPORT_ASM                                   \
+  "s_mov_b32 %[sm0], m0\n\t"                                   \
+  "s_mov_b64 %[sx], exec\n"                                     \
+  "1:\n\t"                                                      \
+  "s_ff1_i32_b64 %[sb], %[mine]\n\t"                            \
+  "v_readlane_b32 %[sr], %[r], %[sb]\n\t"                       \
+  "s_bitset0_b64 %[mine], %[sb]\n\t"                            \
+  "s_bfe_u32 %[sl], %[sr], 0x60004\n\t"                         \
+  "s_lshr_b32 %[sidx], %[sr], 13\n\t"                           \
+  "s_and_b32 %[sr], %[sr], 15\n\t"                              \
+  "s_lshl4_add_u32 %[sidx], %[sidx], %[sr]\n\t"                 \
+  "s_set_gpr_idx_on %[sidx], gpr_idx(SRC0)\n\t"                 \
+  "v_mov_b32 %[vt], v16\n\t"                                    \
+  "s_set_gpr_idx_off\n\t"                                       \
+  "v_readlane_b32 %[sv], %[vt], %[sl]\n\t"                      \
+  "s_lshl_b64 exec, 1, %[sb]\n\t"                               \
+  "v_mov_b32 %[res], %[sv]\n\t"                                 \
+  "s_mov_b64 exec, %[sx]\n\t"                                   \
+  "s_cmp_lg_u64 %[mine], 0\n\t"                                 \
+  "s_cbranch_scc1 1b\n\t"                                       \
+  "s_mov_b32 m0, %[sm0]\n"
+#define SLIM_GRAMR_EXPORT_OUT                                                                           \
+  [res] "+v"(res), [mine] "+s"(mine), [sb] "=&s"(sb), [sr] "=&s"(sr), [sl] "=&s"(sl), [sidx] "=&s"(sidx), \
+      [sv] "=&s"(sv), [vt] "=&v"(vt), [sm0] "=&s"(sm0), [sx] "=&s"(sx)
+template <int KRA>
+__device__ __forceinline__ float gramr_export(GramrRegs<KRA>& gr, const int r, uint64_t mine) {
+  float res = 0.0f, vt;
+  int sb, sr, sl, sidx, sm0;
+  float sv;
+  uint64_t sx;
+  static_assert(KRA == 1 || KRA == 3 || KRA == 6 || KRA == 10, "one operand list per instantiation");
+  if constexpr (KRA == 1) {
+    asm volatile(SLIM_GRAMR_EXPORT_ASM : SLIM_GRAMR_EXPORT_OUT : [r] "v"(r), "{v[16:31]}"(gramr_reg<0>(gr)) : "scc");
+  } else if constexpr (KRA == 3) {
+    asm volatile(SLIM_GRAMR_EXPORT_ASM
+                 : SLIM_GRAMR_EXPORT_OUT
+                 : [r] "v"(r), "{v[16:31]}"(gramr_reg<0>(gr)), "{v[32:47]}"(gramr_reg<1>(gr)),
+                   "{v[48:63]}"(gramr_reg<2>(gr))
+                 : "scc");
+  } else if constexpr (KRA == 6) {
+    asm volatile(SLIM_GRAMR_EXPORT_ASM
+                 : SLIM_GRAMR_EXPORT_OUT
+                 : [r] "v"(r), "{v[16:31]}"(gramr_reg<0>(gr)), "{v[32:47]}"(gramr_reg<1>(gr)),
+                   "{v[48:63]}"(gramr_reg<2>(gr)), "{v[64:79]}"(gramr_reg<3>(gr)), "{v[80:95]}"(gramr_reg<4>(gr)),
+                   "{v[96:111]}"(gramr_reg<5>(gr))
+                 : "scc");
+  } else {
+    asm volatile(SLIM_GRAMR_EXPORT_ASM
+                 : SLIM_GRAMR_EXPORT_OUT
+                 : [r] "v"(r), "{v[16:31]}"(gramr_reg<0>(gr)), "{v[32:47]}"(gramr_reg<1>(gr)),
+                   "{v[48:63]}"(gramr_reg<2>(gr)), "{v[64:79]}"(gramr_reg<3>(gr)), "{v[80:95]}"(gramr_reg<4>(gr)),
+                   "{v[96:111]}"(gramr_reg<5>(gr)), "{v[112:127]}"(gramr_reg<6>(gr)),
+                   "{v[128:143]}"(gramr_reg<7>(gr)), "{v[144:159]}"(gramr_reg<8>(gr)),
+                   "{v[160:175]}"(gramr_reg<9>(gr))
+                 : "scc");
+  }
+  return res;
+}
+
 // KR groups of 8192 ranks in registers, KL groups in LDS (dynamic: KL * 32 KB).
 // DMA: the row is streamed into a per-wavefront LDS ring by `global_load_lds_dwordx4` (LDS-DMA: no
 // VGPR holds data in flight) kGramrAhead groups ahead of the one being decoded, instead of GRP
@@ -335,6 +415,13 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     const bool my_wave = (((r >> 4) & (NT - 1)) >> 6) == wave;
     if (KR > 0) {
       uint64_t mine = __ballot(want && !in_lds && my_wave);
+#if SLIM_GRAMR_ASMEXPORT
+      if (mine) {
+        const bool own = want && !in_lds && my_wave;
+        const float res = gramr_export<KRA>(gr, r, mine);
+        if (own) gb[lane] = res;
+      }
+#else
       while (mine) {
         const int b = __builtin_ctzll(mine);
         mine &= mine - 1ull;
@@ -342,6 +429,7 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         const float v = gramr_sel<KRA>(gr, rb >> 13, rb & 15);
         if (lane == ((rb >> 4) & 63)) gb[b] = v;
       }
+#endif
     }
     if (KL > 0 && want && in_lds && my_wave) gb[lane] = g_lds[lds_index(r)];
 #if SLIM_GRAMR_PROF
