@@ -330,8 +330,8 @@ __global__ __launch_bounds__(64 * NW, (V == 0 && NW == 8) ? 4 : 1) void cd_gram_
             uint64_t pend = __ballot(part[sl]);
             while (pend) {
               const float xeff = (xi[sl] > kEps || xi[sl] < -kEps) ? xi[sl] : 0.0f;
-              const float num = gi[sl] + xeff * sq[sl];
-              const float nx = num > l1 ? (num - l1) / (cn[sl] * cn[sl] + l2) : 0.0f;
+              const float num = cd_num(gi[sl], xeff, sq[sl]);
+              const float nx = num > l1 ? (num - l1) / cd_den(cn[sl], l2) : 0.0f;
               const float neff = (nx > kEps || nx < -kEps) ? nx : 0.0f;
               const float d = neff - xeff;
               const uint64_t m = __ballot(part[sl] && nx != xi[sl]) & pend;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64 * NW, (V == 0 && NW == 8) ? 4 : 1) void cd_gram_
               const int i_f = lane_bcast(i[sl], f);
               const float d_f = lane_bcast(d, f);
               const float nx_f = lane_bcast(nx, f), xi_f = lane_bcast(xi[sl], f);
-              dlt += (nx_f - xi_f) * (nx_f - xi_f);
+              dlt = fmaf(nx_f - xi_f, nx_f - xi_f, dlt);
               if (wave == 0 && lane == f) x[i[sl]] = nx;
               pend = f == 63 ? 0ull : (pend & ~((2ull << f) - 1ull));
               if (d_f != 0.0f) {
@@ -427,8 +427,8 @@ __global__ __launch_bounds__(64 * NW, (V == 0 && NW == 8) ? 4 : 1) void cd_gram_
         Dq += (unsigned long long)len;
         while (pend) {
           const float xeff = (xi > kEps || xi < -kEps) ? xi : 0.0f;
-          const float num = gi + xeff * sq;
-          const float nx = num > l1 ? (num - l1) / (cn * cn + l2) : 0.0f;
+          const float num = cd_num(gi, xeff, sq);
+          const float nx = num > l1 ? (num - l1) / cd_den(cn, l2) : 0.0f;
           const float neff = (nx > kEps || nx < -kEps) ? nx : 0.0f;
           const float d = neff - xeff;
           const uint64_t m = __ballot(part && nx != xi) & pend;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64 * NW, (V == 0 && NW == 8) ? 4 : 1) void cd_gram_
           const int i_f = lane_bcast(i, f);
           const float d_f = lane_bcast(d, f);
           const float nx_f = lane_bcast(nx, f), xi_f = lane_bcast(xi, f);
-          dlt += (nx_f - xi_f) * (nx_f - xi_f);
+          dlt = fmaf(nx_f - xi_f, nx_f - xi_f, dlt);
           if (wave == 0 && lane == f) x[i] = nx;
           pend = f == 63 ? 0ull : (pend & ~((2ull << f) - 1ull));
           if (d_f != 0.0f) {

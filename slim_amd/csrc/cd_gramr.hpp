@@ -259,7 +259,9 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     // even full)
     uint32_t bwords[4];
     if constexpr (DMA) {
-      __builtin_amdgcn_global_load_lds(pbase + voff0, ring_w + (kGramrAhead + 1) * 1024, 16, 0, 0);
+      uint32_t vzb = voff0;
+      asm volatile("" : "+v"(vzb));
+      __builtin_amdgcn_global_load_lds(pbase + vzb, ring_w + (kGramrAhead + 1) * 1024, 16, 0, 0);
     } else {
       const uint4 bw = ld_off<uint4>(pbase, voff0);
       bwords[0] = bw.x;
@@ -294,7 +296,9 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       if (k < hk) {
         unpack16_add(hi_of(), 256.0f, f);
         if (k < h2k) {
-          const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
+          uint32_t vz = voff0;
+          asm volatile("" : "+v"(vz));
+          const uint32_t vo = min(vz + (uint32_t)(kPackGroup * k), vlast);
           unpack16_add(ld_off<uint4>(ph2, vo), 65536.0f, f);
         }
       }
@@ -337,9 +341,14 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
           if (k < hk) h01[k] = ld_off<uint4>(phi, min(voff0 + (uint32_t)(kPackGroup * k), vlast));
         }
       });
+      // (the byte offset of a request is recomputed from an opaque copy of the thread's offset: left
+      // alone the optimizer hoists the thirteen clamped offsets out of the row loop and keeps them,
+      // zero-extended to 64 bits for the request's address, in 26 VGPRs -- round 6, seen in the ISA)
       auto request = [&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        const uint32_t vo = min(voff0 + (uint32_t)(kPackGroup * k), vlast);
+        uint32_t vz = voff0;
+        asm volatile("" : "+v"(vz));
+        const uint32_t vo = min(vz + (uint32_t)(kPackGroup * k), vlast);
         // (aux = SLIM_GRAMR_AUX: 2 = nt, a row is read once by one CU -- MI355X guide, "nt-weights")
         __builtin_amdgcn_global_load_lds(plo + vo, ring_w + (k % S) * 1024, 16, 0, SLIM_GRAMR_AUX);
       };
@@ -365,7 +374,11 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         const uint4 lo = *reinterpret_cast<const uint4*>(ring_w + (k % S) * 1024 + lane * 16);
         consume(kc, lo, [&]() __attribute__((always_inline)) -> uint4 {
           if constexpr (k < 2) return h01[k];
-          else return ld_off<uint4>(phi, min(voff0 + (uint32_t)(kPackGroup * k), vlast));
+          else {
+            uint32_t vz = voff0;
+            asm volatile("" : "+v"(vz));
+            return ld_off<uint4>(phi, min(vz + (uint32_t)(kPackGroup * k), vlast));
+          }
         });
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -662,8 +675,8 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
           // equals cnorm[i], gram_pack_meta) -- setup.c:130's rounded norm, squared again (cd.c:127)
           const float sq = __uint_as_float(mrow.w);
           const float cn = sqrtf(sq);
-          const float num = gi + xeff * sq;
-          const float nx = num > l1 ? (num - l1) / (cn * cn + l2) : 0.0f;
+          const float num = cd_num(gi, xeff, sq);
+          const float nx = num > l1 ? (num - l1) / cd_den(cn, l2) : 0.0f;
           const float neff = (nx > kEps || nx < -kEps) ? nx : 0.0f;
           const float d = neff - xeff;
           const uint64_t m = __ballot(part && nx != xi) & pend;
@@ -671,7 +684,7 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
           const int f = __builtin_ctzll(m);
           const float d_f = lane_bcast(d, f);
           const float nx_f = lane_bcast(nx, f), xi_f = lane_bcast(xi, f);
-          dlt += (nx_f - xi_f) * (nx_f - xi_f);
+          dlt = fmaf(nx_f - xi_f, nx_f - xi_f, dlt);
           row = lane_bcast(i, f);
           // (addressed by the uniform `row`: a per-lane &x[i] kept for this store was spilled, and its
           // reload put a scratch latency and a full drain in front of every update of wavefront 0)

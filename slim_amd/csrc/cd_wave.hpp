@@ -140,6 +140,18 @@ constexpr float kEps = 1e-7f;  // def.h:14
 
 // ---- wave-level primitives ---------------------------------------------------
 
+// The update rule's arithmetic in the item-space kernels (cd_gram.hpp, cd_gramr.hpp, cd_gramrp.hpp),
+// spelled out: left to -ffp-contract, `g + x * sq` came out as a multiply and an add in one kernel
+// (the product hoisted out of a loop) and as one fma in another -- models an ulp apart, where the
+// tests ask for equal bits.  The product is rounded, then the sum; the denominator is one fma.
+// (__fmul_rn / __fadd_rn are ordinary operations to the optimizer, which fused them all the same:
+// the product passes through an empty asm)
+__device__ __forceinline__ float cd_num(float g, float xeff, float sq) {
+  float p = xeff * sq;
+  asm volatile("" : "+v"(p));
+  return g + p;
+}
+__device__ __forceinline__ float cd_den(float cn, float l2) { return fmaf(cn, cn, l2); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);

@@ -22,9 +22,9 @@ GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes)
   else if (k <= 6) { *kr = 6; fn = dma ? cd_gramr_kernel<6, 0, true> : cd_gramr_kernel<6, 0, false>; }
   else if (k <= kGramrMaxGroups) {
     static_assert(kGramrMaxGroups == 10 + 3, "the largest instantiation below");
-    // <10, 3>: one form, chosen at build time (gramr_k13.hip: the LDS ring, 4 slots)
     *kr = 10;
     *kl = 3;
+    // <10, 3>: one form, chosen at build time (gramr_k13.hip: the LDS ring, 4 slots)
     fn = gramr_kernel_k13(&dma, &ring_ah);
   }
   *lds_bytes = sizeof(float) * (size_t)*kl * kPackGroup + (dma ? (size_t)gramr_ring_bytes(ring_ah) : 0) + (size_t)gramr_hdr_bytes();
