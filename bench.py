@@ -24,10 +24,12 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
                 itself cannot be built here) timed on a bounded sample of the same columns
 and, at N = 1 on the default workload, two secondary figures under their own keys (never
 `value`; SURVEY.md 8(d)'s formula does not price them):
-  item_space_step  the last timed step once more, from scratch, in item space (cd_gram.hpp;
-                   G = R^T R built inside the measured time), with the difference of the models
+  item_space_step  up to five of the timed steps' column ranges once more, from scratch, in item
+                   space (cd_gramr.hpp; G = R^T R built inside the first one's measured time and
+                   reported apart and amortised), with the difference of the models
   item_space_grid  the first pairs of the C5 model-selection grid (BASELINE.json configs[4])
                    on the path the engine takes for a grid
+  item_space_whole_matrix  every item column of the matrix once (north_star's target at N = 1)
 The command budgets itself against the driver's 1800 s (SLIM_BENCH_WALL_BUDGET): the extras
 and the CPU leg shrink or drop out, with a note, rather than overrun.
 """
@@ -247,9 +249,11 @@ def main():
     t0 = time.perf_counter()
     acc = dict(kernel_ms=0.0, alg_bytes=0.0, G=0, D=0, U=0, nnzW=0, sweeps=0, gather_ms=0.0)
     last_b = None
+    step_begins = []
     for i in range(args.steps):
         W, st, b = step(args.warmup + i, span)
         last_b = b  # W holds the columns of THIS step: the CPU leg must sample from it
+        step_begins.append(b)
         for k in acc:
             acc[k] += st[k]
     fence()
@@ -314,6 +318,7 @@ def main():
                         "value": ncols / float(tw.item()), "unit": "item-columns/s",
                         "kernel": KERNEL_NAMES.get(stw["kernel"], stw["kernel"]),
                         "G_build_s": round(stw["gram_build_ms"] * 1e-3, 2),
+                        "G_build_split_s": gram_split(stw) if stw["gram_build_ms"] else None,
                         "G_sharded_s": [round(x, 3) for x in gram_s] if gram_s else None}
             except Exception as e:   # noqa: BLE001
                 return {"error": "%s: %s" % (type(e).__name__, e)}
@@ -403,8 +408,16 @@ def main():
         # BEFORE the CPU leg, which fits itself into whatever is left of the wall budget)
         if world == 1 and args.workload == "c4" and args.scale == 1 and args.kernel != 5 \
                 and not args.no_item_space and WALL_BUDGET_S - (time.time() - T_START) > 200:
-            out["item_space_step"] = item_space_step(args, mat, last_b, span, opts, W)
+            out["item_space_step"] = item_space_step(args, mat, step_begins, span, opts, W)
             out["item_space_grid"] = item_space_grid(args, dev)
+            # north_star's literal target at N = 1: every item column of the matrix, on the path
+            # SLIM_Learn takes (G is on the handle by now: its cost is item_space_step's G_build_s)
+            left = WALL_BUDGET_S - (time.time() - T_START)
+            if left > 150 and not args.no_whole_matrix:
+                out["item_space_whole_matrix"] = item_space_whole_matrix(args, mat, ncols, opts,
+                                                                         out["item_space_step"])
+            else:
+                out["item_space_whole_matrix"] = {"skipped": "%.0f s of the wall budget left (needs 150)" % left}
         if world == 1 and args.cpu_seconds > 0 and args.workload != "ml100k":
             out["cpu_baseline"] = cpu_baseline(args, mat, rowptr, rowind, rowval, nrows, ncols,
                                                last_b, span, opts, W)
@@ -496,41 +509,124 @@ def dry_run(args, mat, ncols, per_gpu, opts, nnz):
                     "is measured is the evenness of the shards and the step time they imply"}
 
 
-def item_space_step(args, mat, b, span, opts, W_res):
-    """Secondary figure, under its own key: the LAST timed step once more -- the same columns of
-    the same matrix, from scratch -- on the path SLIM_Learn takes by default (SLIMGPU_KERNEL_AUTO:
-    item space, cd_gram*.hpp): G = R^T R of the whole matrix is built inside the measured time and
-    nothing is carried in.  Also a parity figure: the two kernels walk the same visiting order, so
-    their models differ by fp32 rounding only.  Its roofline object uses that kernel's own byte
-    model (bytes of G streamed, SLIMGPU_LastStats.gram_bytes) over its HIP-event time."""
+def gram_split(st):
+    """The parts of SLIMGPU_LastStats.gram_build_ms, in seconds (slim_gpu.h): the allocation of G
+    (a first 40 GB hipMalloc costs seconds on some boxes and nothing on others -- what made the same
+    build 2.7 s in one record and 5.7 s in another), the sums (the whole nested solve, and its kernel
+    alone), the byte planes."""
+    return {"allocation": round(st.get("gram_alloc_ms", 0.0) * 1e-3, 2),
+            "sums": round(st.get("gram_sums_ms", 0.0) * 1e-3, 2),
+            "sums_kernel": round(st.get("gram_sums_kernel_ms", 0.0) * 1e-3, 2),
+            "byte_planes": round(st.get("gram_pack_ms", 0.0) * 1e-3, 2)}
+
+
+def item_space_step(args, mat, begins, span, opts, W_res, nmax=5):
+    """Secondary figure, under its own key: up to `nmax` of the timed steps once more -- the same
+    column ranges of the same matrix, from scratch -- on the path SLIM_Learn takes by default
+    (SLIMGPU_KERNEL_AUTO: item space, cd_gramr.hpp).  The LAST timed step comes first: it builds
+    G = R^T R of the whole matrix inside its measured time (nothing is carried in) and is compared
+    with the timed step's model (the two kernels walk the same visiting order: fp32 rounding only);
+    the other ranges then run with G on the handle, as every solve after the first does.  `value` /
+    `seconds` are the first (from-scratch) step's, as in round 5; `steps` has every range, `mean` /
+    `min` / `max` over their solve times, `value_amortised` = all columns / (all solves + G once).
+    The roofline object uses the kernel's own byte model (bytes of G streamed,
+    SLIMGPU_LastStats.gram_bytes) over its HIP-event time, summed over the ranges."""
     import scipy.sparse as sp
     saved = {k: os.environ.pop(k, None) for k in ("SLIM_GPU_NO_GRAM", "SLIM_GPU_NO_GRAMCD")}
     try:
-        t0 = time.perf_counter()
-        Wi, st = mat.learn(col_begin=b, col_end=b + span, **dict(opts, kernel=0))
-        dt = time.perf_counter() - t0
-        d = abs(sp.csc_matrix(Wi) - sp.csc_matrix(W_res))
+        order = [begins[-1]] + [x for x in dict.fromkeys(reversed(begins[:-1]))][:nmax - 1]
+        recs, first = [], None
+        bytes_sum = ks_sum = 0.0
+        for j, b in enumerate(order):
+            t0 = time.perf_counter()
+            Wi, st = mat.learn(col_begin=b, col_end=b + span, **dict(opts, kernel=0))
+            dt = time.perf_counter() - t0
+            ks = st["kernel_ms"] * 1e-3
+            if j == 0:
+                d = abs(sp.csc_matrix(Wi) - sp.csc_matrix(W_res))
+                first = (dt, st, float(d.max()) if d.nnz else 0.0)
+            del Wi
+            bytes_sum += st["gram_bytes"]
+            ks_sum += ks
+            recs.append({"col_begin": int(b), "seconds": round(dt, 2), "kernel_s": round(ks, 3),
+                         "solve_s": round(dt - st["gram_build_ms"] * 1e-3, 2),
+                         "G_build_s": round(st["gram_build_ms"] * 1e-3, 2),
+                         "row_GBps": round(st["gram_bytes"] / max(ks, 1e-9) / 1e9, 1),
+                         "alg_bytes": st["gram_bytes"], "nnzW": int(st["nnzW"])})
+        dt, st, dmax = first
         ks = st["kernel_ms"] * 1e-3
-        gbps = st["gram_bytes"] / max(ks, 1e-9) / 1e9
+        gbps = bytes_sum / max(ks_sum, 1e-9) / 1e9
         traffic = pmc_traffic(args, span, "item_space_step", True)
+        solves = [r["solve_s"] for r in recs]
+        kernels = [r["kernel_s"] for r in recs]
+        g_s = st["gram_build_ms"] * 1e-3
         return {"columns": int(span), "seconds": round(dt, 2), "value": span / dt, "unit": "item-columns/s",
-                "G_build_s": round(st["gram_build_ms"] * 1e-3, 2), "kernel_s": round(ks, 2),
+                "G_build_s": round(g_s, 2), "G_build_split_s": gram_split(st), "kernel_s": round(ks, 2),
                 "rows_of_G_read": int(st["gram_rows"]), "kernel": KERNEL_NAMES.get(st["kernel"], st["kernel"]),
                 "chosen_by": "SLIMGPU_KERNEL_AUTO (the engine's default)",
-                "max_abs_dW_vs_the_timed_step": float(d.max()) if d.nnz else 0.0,
+                "max_abs_dW_vs_the_timed_step": dmax,
                 "nnzW": int(st["nnzW"]),
+                "steps": recs,
+                "solve_s": {"mean": round(sum(solves) / len(solves), 3), "min": min(solves), "max": max(solves)},
+                "kernel_s_per_step": {"mean": round(sum(kernels) / len(kernels), 3), "min": min(kernels),
+                                      "max": max(kernels)},
+                "value_G_resident": span * len(recs) / max(sum(solves), 1e-9),
+                "value_amortised": span * len(recs) / max(sum(solves) + g_s, 1e-9),
                 "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": gbps / HBM_PEAK_GBS,
                              "traffic": float(traffic) if traffic else None,
                              "achieved_physical": float(traffic) / ks / 1e9 if traffic and ks > 0 else None,
-                             "kernel_ms_per_launch": st["kernel_ms"], "alg_bytes_per_launch": st["gram_bytes"],
+                             "kernel_ms_per_launch": 1e3 * ks_sum / len(recs),
+                             "alg_bytes_per_launch": bytes_sum / len(recs),
+                             "launches": len(recs),
                              "note": "byte model of the item-space kernel: the bytes of G its updates and "
                                      "warm-start folds stream (SLIMGPU_LastStats.gram_bytes) over the solver's "
-                                     "HIP-event time (union lists included); traffic: PMC bytes of the same "
-                                     "launch (profiles/pmc_traffic.json, matched by configuration and source hash)"},
-                "note": "the columns of the last timed step, from scratch, G = R^T R (all 100 000 items) built "
-                        "inside `seconds`; not `value`: SURVEY.md 8(d) prices the residual kernel's traffic"}
+                                     "HIP-event time (union lists included), summed over the ranges; traffic: PMC "
+                                     "bytes of the first range's launch (profiles/pmc_traffic.json, matched by "
+                                     "configuration and source hash)"},
+                "note": "column ranges of the timed steps, from scratch, on the engine's default path; G = R^T R "
+                        "(all 100 000 items) is built inside the first range's `seconds` and reported apart "
+                        "(G_build_s) and amortised (value_amortised); not `value`: SURVEY.md 8(d) prices the "
+                        "residual kernel's traffic"}
     except Exception as e:   # noqa: BLE001 -- an extra must not cost the line
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+
+
+def item_space_whole_matrix(args, mat, ncols, opts, step_rec):
+    """Secondary figure, under its own key: north_star's literal target on one GPU -- every item
+    column of the 1M x 100K matrix solved once, on the engine's default path (item space; G is on
+    the handle: item_space_step paid for it, and `seconds_with_G` adds that cost back).  Its
+    roofline object is the one launch's bytes of G over its HIP-event time."""
+    saved = {k: os.environ.pop(k, None) for k in ("SLIM_GPU_NO_GRAM", "SLIM_GPU_NO_GRAMCD")}
+    try:
+        t0 = time.perf_counter()
+        Ww, st = mat.learn(col_begin=0, col_end=ncols, **dict(opts, kernel=0))
+        dt = time.perf_counter() - t0
+        nnzw = int(Ww.nnz)
+        del Ww
+        ks = st["kernel_ms"] * 1e-3
+        gbps = st["gram_bytes"] / max(ks, 1e-9) / 1e9
+        g_s = st["gram_build_ms"] * 1e-3 or (step_rec or {}).get("G_build_s", 0.0)
+        traffic = pmc_traffic(args, ncols, "item_space_whole_matrix", True)
+        return {"columns": int(ncols), "seconds": round(dt, 2), "value": ncols / dt, "unit": "item-columns/s",
+                "seconds_with_G": round(dt + (0.0 if st["gram_build_ms"] else g_s), 2),
+                "value_with_G": ncols / (dt + (0.0 if st["gram_build_ms"] else g_s)),
+                "G_build_s": round(g_s, 2), "kernel_s": round(ks, 2),
+                "host_s": round(dt - ks - st["gram_build_ms"] * 1e-3, 2),
+                "rows_of_G_read": int(st["gram_rows"]), "nnzW": nnzw,
+                "kernel": KERNEL_NAMES.get(st["kernel"], st["kernel"]),
+                "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": gbps / HBM_PEAK_GBS,
+                             "traffic": float(traffic) if traffic else None,
+                             "achieved_physical": float(traffic) / ks / 1e9 if traffic and ks > 0 else None,
+                             "kernel_ms_per_launch": st["kernel_ms"], "alg_bytes_per_launch": st["gram_bytes"]},
+                "note": "all item columns of the matrix in one SLIMGPU_Learn on the engine's default path "
+                        "(north_star's target at N = 1); host_s = D2H + assembly of the model"}
+    except Exception as e:   # noqa: BLE001
         return {"error": "%s: %s" % (type(e).__name__, e)}
     finally:
         for k, v in saved.items():
@@ -572,6 +668,7 @@ def item_space_grid(args, dev, npairs=3):
             recs.append({"l1": l1, "l2": l2, "seconds": round(dt, 2),
                          "kernel_s": round(st["kernel_ms"] * 1e-3, 2),
                          "G_build_s": round(st["gram_build_ms"] * 1e-3, 2),
+                         "G_build_split_s": gram_split(st) if st["gram_build_ms"] else None,
                          "kernel": KERNEL_NAMES.get(st["kernel"], st["kernel"]),
                          "sweeps_per_column": round(st["sweeps"] / float(ncols), 2),
                          "rows_of_G_read": int(st["gram_rows"]),

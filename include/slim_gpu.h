@@ -249,6 +249,11 @@ typedef struct slimgpu_stats_t {
                               float kernels, the packed rows' bytes (counted on the device)
                               for the byte-plane kernel: the item-space byte model (it does
                               not move what SURVEY.md 8(d)'s alg_bytes prices)  */
+  /* gram_build_ms split (round 6; appended: older callers read a prefix): the allocation of
+     G (a first 40 GB hipMalloc costs seconds on some boxes and nothing on others), the
+     sums -- the whole nested solve that forms them, and its kernel alone -- and the byte
+     planes                                                                            */
+  double gram_alloc_ms, gram_sums_ms, gram_sums_kernel_ms, gram_pack_ms;
 } slimgpu_stats_t;
 int32_t SLIMGPU_LastStats(slimgpu_stats_t *out);
 

@@ -35,6 +35,10 @@ cd $R
 if [ -z "${SKIP_PMC:-}" ] && grep -q '"item_space_step": {"columns"' $O/${TAG}_pmc_FETCH_SIZE.json 2>/dev/null; then
   PMC_ITEM_SPACE=1 python scripts/pmc_to_json.py $O/${TAG}_pmc_FETCH_SIZE/run_counter_collection.csv $O/${TAG}_pmc_WRITE_SIZE/run_counter_collection.csv \
     $O/cal_FETCH_SIZE/cal_counter_collection.csv $O/cal_WRITE_SIZE/cal_counter_collection.csv $O/${TAG}_pmc_FETCH_SIZE.json > $O/${TAG}_pmc_entry_item_space.json
+  if grep -q '"item_space_whole_matrix": {"columns"' $O/${TAG}_pmc_FETCH_SIZE.json 2>/dev/null; then
+    PMC_ITEM_SPACE=whole python scripts/pmc_to_json.py $O/${TAG}_pmc_FETCH_SIZE/run_counter_collection.csv $O/${TAG}_pmc_WRITE_SIZE/run_counter_collection.csv \
+      $O/cal_FETCH_SIZE/cal_counter_collection.csv $O/cal_WRITE_SIZE/cal_counter_collection.csv $O/${TAG}_pmc_FETCH_SIZE.json > $O/${TAG}_pmc_entry_item_space_whole.json
+  fi
 fi
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 grep trace $O/${TAG}_bench.err 2>/dev/null | cut -c1-400

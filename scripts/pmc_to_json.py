@@ -22,12 +22,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def counter(path, kernel_substr, name, take=None):
     """Sum of a counter over the dispatches of a kernel (take: only the first `take` of them in
-    time order -- the bench command's extras launch the tile kernel again to build G)."""
+    time order -- the bench command's extras launch the tile kernel again to build G; take < 0:
+    the last -take of them)."""
     rows = [r for r in csv.DictReader(open(path))
             if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == name]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     if take is not None:
-        rows = rows[:take]
+        rows = rows[:take] if take >= 0 else rows[take:]
     tot = sum(float(r["Counter_Value"]) for r in rows)
     secs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9 for r in rows]
     return tot, len(rows), secs
@@ -45,7 +46,9 @@ def main():
     kname = "cd_tile_kernel" if cfg["kernel"].startswith("tile") else "cd_wave_kernel"
     item_space = os.environ.get("PMC_ITEM_SPACE")   # entry for the item_space_step launch of the same run
     take = int(bench.get("steps", 1))
-    if item_space:
+    if item_space == "whole":   # the whole-matrix launch: the last dispatch of the item-space kernel
+        kname, take = "cd_gramr_kernel<10", -1
+    elif item_space:
         kname, take = "cd_gramr_kernel<10", 1
     f, nf, tf = counter(fetch_csv, kname, "FETCH_SIZE", take)
     w, nw, tw = counter(write_csv, kname, "WRITE_SIZE", take)
@@ -70,9 +73,16 @@ def main():
         # calibration gathers (MI355X_MICROARCH.md, HBM section); same corrections
         sys.path.insert(0, ROOT)
         import bench as B
-        entry["match"]["kernel"] = "item_space_step"
         entry["kernel_hash"] = B.kernel_hash("gram")
-        entry["alg_bytes_per_launch_same_run"] = bench["item_space_step"]["roofline"]["alg_bytes_per_launch"]
+        if item_space == "whole":
+            entry["match"]["kernel"] = "item_space_whole_matrix"
+            entry["match"]["columns_per_step_per_gpu"] = bench["item_space_whole_matrix"]["columns"]
+            entry["alg_bytes_per_launch_same_run"] = bench["item_space_whole_matrix"]["roofline"]["alg_bytes_per_launch"]
+        else:
+            entry["match"]["kernel"] = "item_space_step"
+            # (the first range's launch: the bytes of that launch, not the mean over the ranges)
+            r0 = bench["item_space_step"]["steps"][0]
+            entry["alg_bytes_per_launch_same_run"] = r0["alg_bytes"]
     entry["traffic_over_algorithmic"] = entry["traffic_bytes_per_launch"] / max(
         entry["alg_bytes_per_launch_same_run"], 1.0)
     secs = entry["kernel_seconds_under_pmc"]

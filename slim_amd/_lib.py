@@ -28,7 +28,9 @@ class Stats(C.Structure):
                 ("G", C.c_int64), ("D", C.c_int64), ("U", C.c_int64), ("nnzW", C.c_int64),
                 ("sweeps", C.c_int64), ("visits", C.c_int64), ("alg_bytes", C.c_double),
                 ("error", C.c_double), ("objval", C.c_double), ("gram_build_ms", C.c_double),
-                ("gram_rows", C.c_int64), ("gram_bytes", C.c_double)]
+                ("gram_rows", C.c_int64), ("gram_bytes", C.c_double),
+                ("gram_alloc_ms", C.c_double), ("gram_sums_ms", C.c_double),
+                ("gram_sums_kernel_ms", C.c_double), ("gram_pack_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

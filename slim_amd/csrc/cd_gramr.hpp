@@ -43,6 +43,9 @@
 #ifndef SLIM_GRAMR_PROF
 #define SLIM_GRAMR_PROF 0
 #endif
+#ifndef SLIM_GRAMR_LATE_GATHERS  // (A/B: 0 = the gathers in front of the row's head, as in round 5)
+#define SLIM_GRAMR_LATE_GATHERS 1
+#endif
 // bisect switches of scripts/gramr_k13_sweep.py (A/B builds only; all 0 in the product):
 #ifndef SLIM_GRAMR_DRAIN     // every ring wait drains everything outstanding
 #define SLIM_GRAMR_DRAIN 0
@@ -247,10 +250,22 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
 #endif
   char* const hdr_w = reinterpret_cast<char*>(g_lds) + KL * kPackGroup * 4 + (DMA ? gramr_ring_bytes(AH) : 0) +
                       wave * (2 * kGramrHdr);
+  // (rg: the rank whose entry of this row every lane gathers -- its own visit's; gq: the four bytes)
   auto apply = [&](const uint8_t* __restrict__ plo, const uint8_t* __restrict__ phi,
                    const uint8_t* __restrict__ ph2, const uint8_t* __restrict__ pbase, const int hk,
                    const int h2k, const int cdiag, const int ediag, const float vdiag,
-                   const float nd) __attribute__((always_inline)) {
+                   const float nd, const int rg, uint32_t (&gq)[4]) __attribute__((always_inline)) {
+    const bool gin1 = rg < hk * kPackGroup, gin2 = rg < h2k * kPackGroup;
+    auto gathers = [&]() __attribute__((always_inline)) {
+      // relaxed atomic loads of wavefront scope: ordinary global_load_ubyte in the ISA, but they stay
+      // where they are written -- the ring's wait counts below include them
+      gq[0] = __hip_atomic_load(plo + rg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      gq[1] = __hip_atomic_load(phi + (gin1 ? rg : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      gq[2] = __hip_atomic_load(ph2 + (gin2 ? rg : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      gq[3] = __hip_atomic_load(pbase + (((rg >> 4) & (NT - 1)) * 16 + (rg >> 13)), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+    if constexpr (!(DMA && SLIM_GRAMR_LATE_GATHERS)) gathers();
     // the base bytes of this thread's chunks (byte k: chunk tid + 512 k; 0 inside the hi prefix)
     const int kdiag = cdiag / NT, tdiag = cdiag % NT;  // (uniform: the group test is a scalar branch)
     // (with the ring they come by LDS-DMA too, ahead of the row's first group: as a register load
@@ -353,13 +368,18 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         __builtin_amdgcn_global_load_lds(plo + vo, ring_w + (k % S) * 1024, 16, 0, SLIM_GRAMR_AUX);
       };
       static_for<(kGramrAhead < K ? kGramrAhead : K)>([&](auto kc) __attribute__((always_inline)) { request(kc); });
+      // (round 6) the lanes' four byte gathers BEHIND the ring's first requests: in front of them they
+      // were older than group 0, whose wait then waited for four scattered single-byte loads too
+      constexpr int kLate = SLIM_GRAMR_LATE_GATHERS ? 4 : 0;
+      if constexpr (SLIM_GRAMR_LATE_GATHERS) gathers();
       static_for<K>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         if constexpr (k + kGramrAhead < K) request(std::integral_constant<int, k + kGramrAhead>{});
         // loads complete in order: once at most `ahead` requests (the groups behind this one) are
         // outstanding, group k has landed
         constexpr int ahead = (K - 1 - k) < kGramrAhead ? (K - 1 - k) : kGramrAhead;
-        SLIM_VMCNT(ahead);
+        // (the late gathers sit between request AH - 1 and request AH: younger than the first AH groups)
+        SLIM_VMCNT(ahead + (k < kGramrAhead ? kLate : 0));
         asm volatile("" ::: "memory");
         if constexpr (k == 0) {  // (requested before group 0: landed with it)
           const uint4 bw = *reinterpret_cast<const uint4*>(ring_w + (kGramrAhead + 1) * 1024 + lane * 16);
@@ -717,17 +737,16 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         // a visit's lane: the entry of the row its own coordinate needs (four byte loads issued
         // together, ahead of the row; behind a plane's prefix the lane reads byte 0 and drops it)
         const bool in1 = r < hk * kPackGroup, in2 = r < h2k * kPackGroup;
-        const uint32_t b0 = plo[r], b1 = phi[in1 ? r : 0], b2 = ph2[in2 ? r : 0];
-        const uint32_t b3 = pbase[((r >> 4) & (NT - 1)) * 16 + (r >> 13)];
+        uint32_t gq[4];
         const int rdiag = (int)(rec.x & 0x1FFFFu);
         SLIM_PT(pt_dec)
 #if SLIM_GRAMR_PROF
         pt_mark_v = pt_mark;
 #endif
-        apply(plo, phi, ph2, pbase, hk, h2k, rdiag >> 4, rdiag & 15, __uint_as_float(rec.w), nd);  // (the one site that updates g)
-        float gsel = (float)b0 + 16.0f * (float)b3;
-        gsel = in1 ? fmaf(256.0f, (float)b1, gsel) : gsel;
-        gsel = in2 ? fmaf(65536.0f, (float)b2, gsel) : gsel;
+        apply(plo, phi, ph2, pbase, hk, h2k, rdiag >> 4, rdiag & 15, __uint_as_float(rec.w), nd, r, gq);  // (the one site that updates g)
+        float gsel = (float)gq[0] + 16.0f * (float)gq[3];
+        gsel = in1 ? fmaf(256.0f, (float)gq[1], gsel) : gsel;
+        gsel = in2 ? fmaf(65536.0f, (float)gq[2], gsel) : gsel;
         if (init_row) {  // (the byte model counts updates and folds; this row was the set-up)
           init_row = false;
         } else {

@@ -76,7 +76,7 @@ struct slimgpu_matrix {
   Buf ws_G, ws_nunion;
   int64_t G_ld = 0;
   bool G_ready = false;
-  double G_build_ms = 0;
+  double G_build_ms = 0, G_alloc_ms = 0, G_sums_ms = 0, G_sums_kernel_ms = 0, G_pack_ms = 0;
   // G as byte planes in popularity order (gram_pack.hpp), what cd_gramr.hpp streams: built from
   // the float G right after it, when every entry is a non-negative integer below 2^24
   Buf ws_Glo, ws_Ghi, ws_Ghi2, ws_Gbase, ws_Gdiag, ws_Gmeta, ws_hioff, ws_hi2off, ws_hik, ws_hi2k, ws_rankof, ws_itemof;
@@ -1110,6 +1110,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       m->Gp_tried = false;
       if (!pack_gram(m)) m->Gp_ready = false;
       m->G_build_ms = now_ms() - tb;
+      m->G_alloc_ms = t_alloc - tb;
+      m->G_sums_ms = t_sums - t_alloc;
+      m->G_sums_kernel_ms = sums_kernel_ms;
+      m->G_pack_ms = now_ms() - t_sums;
       if (const char* te = std::getenv("SLIM_GPU_TRACE"); te && std::atoi(te) >= 1)
         std::fprintf(stderr, "[trace] G = R^T R (%d x %d, %.2f GB) built in %.1f ms: allocation %.1f, sums %.1f "
                      "(kernel %.1f), byte planes %.1f\n", ncols, ncols, G_bytes * 1e-9, m->G_build_ms,
@@ -1926,9 +1930,13 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
                        : 8.0 * st.G + 12.0 * st.D + 4.0 * st.U + 8.0 * st.nnzW;
     st.gather_ms = now_ms() - t_kernel_done;
     st.gram_build_ms = use_gram ? m->G_build_ms : 0.0;
+    st.gram_alloc_ms = use_gram ? m->G_alloc_ms : 0.0;
+    st.gram_sums_ms = use_gram ? m->G_sums_ms : 0.0;
+    st.gram_sums_kernel_ms = use_gram ? m->G_sums_kernel_ms : 0.0;
+    st.gram_pack_ms = use_gram ? m->G_pack_ms : 0.0;
     st.gram_rows = gram_rows;
     st.gram_bytes = gram_bytes;
-    if (use_gram) m->G_build_ms = 0.0;  // (charged to the solve that paid for it)
+    if (use_gram) m->G_build_ms = m->G_alloc_ms = m->G_sums_ms = m->G_sums_kernel_ms = m->G_pack_ms = 0.0;  // (charged to the solve that paid for it)
     if (!opt.build_G) m->last_order = requested;
     st.total_ms = now_ms() - t_begin;
     g_stats = st;
