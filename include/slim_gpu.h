@@ -164,6 +164,8 @@ int32_t SLIMGPU_MatrixGetColumnView(const slimgpu_matrix_t *mat, int64_t *colptr
  * G = R^T R for a grid whose single solves would not pay for it (SLIMGPU_KERNEL_GRAM: the
  * automatic choice multiplies the columns of a call by nsolves).  0 withdraws it. */
 void SLIMGPU_MatrixExpectSolves(slimgpu_matrix_t *mat, int32_t nsolves);
+/* The HIP device the handle's buffers live on (-1: null handle). */
+int32_t SLIMGPU_MatrixDevice(const slimgpu_matrix_t *mat);
 
 /* G = R^T R of item-space CD in row blocks, for drivers that run one process per GPU: every rank
  * forms the rows of its block of items (all ncols entries of each: BuildRows), the ranks exchange

@@ -16,16 +16,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def stage(workload, seed=1):
+def stage(workload, seed=1, ratings=False):
+    """ratings: values 1-5 (SURVEY 8(d)'s second C4 run) instead of the binary matrix"""
     import torch
     from slim_amd import synth
     from slim_amd.engine import DeviceMatrix
     dev = torch.device("cuda", 0)
     nrows, ncols, target = synth.CONFIGS[workload]
-    rowptr, rowind, _ = synth.generate_csr(nrows, ncols, target, seed=seed, device=dev)
+    rowptr, rowind, rowval = synth.generate_csr(nrows, ncols, target, seed=seed, ratings=ratings, device=dev)
     torch.cuda.synchronize()
-    return DeviceMatrix.from_device_ptrs(nrows, ncols, rowptr.data_ptr(), rowind.data_ptr(), 0,
-                                         keepalive=(rowptr, rowind), device=0)
+    return DeviceMatrix.from_device_ptrs(nrows, ncols, rowptr.data_ptr(), rowind.data_ptr(),
+                                         rowval.data_ptr() if ratings else 0,
+                                         keepalive=(rowptr, rowind, rowval), device=0)
 
 
 def maxdiff(a, b):
@@ -50,8 +52,10 @@ def main():
     kw = dict(l1r=1.0, l2r=1.0, optTol=1e-7, niters=10000, seed=1, kernel=KERNEL_GRAM)
     if what == "c4":
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-        mat = stage("c4")
-        Wn, sn, cn = run(mat, "c4 %d columns, packed G / g on chip" % n, col_begin=0, col_end=n, **kw)
+        ratings = "--ratings" in sys.argv
+        mat = stage("c4", ratings=ratings)
+        Wn, sn, cn = run(mat, "c4%s %d columns, packed G / g on chip" % (" (ratings 1-5)" if ratings else "", n),
+                         col_begin=0, col_end=n, **kw)
         Wn2, sn2, _ = run(mat, "   again (G there)", col_begin=0, col_end=n, **kw)
         print("   same model twice: %s" % (maxdiff(Wn, Wn2) == 0.0))
         if "--no-float" not in sys.argv:
@@ -61,8 +65,9 @@ def main():
             print("   packed vs float: max|dW| %.3e, sweeps same %.4f, D %d/%d U %d/%d" % (
                 maxdiff(Wn, Wf), (cn.sweeps == cf.sweeps).mean(), cn.D.sum(), cf.D.sum(), cn.U.sum(), cf.U.sum()))
     elif what == "c4all":
-        mat = stage("c4")
-        run(mat, "c4 all columns, packed G / g on chip", **kw)
+        ratings = "--ratings" in sys.argv
+        mat = stage("c4", ratings=ratings)
+        run(mat, "c4%s all columns, packed G / g on chip" % (" (ratings 1-5)" if ratings else ""), **kw)
     elif what == "c5":
         npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 3
         mat = stage("c5")

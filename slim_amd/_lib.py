@@ -88,6 +88,7 @@ _SIGNATURES = {
     "SLIMGPU_MatrixGetColumnView": (C.c_int32, [C.c_void_p] * 5),
     "SLIMGPU_MatrixColumnCost": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "SLIMGPU_MatrixExpectSolves": (None, [C.c_void_p, C.c_int32]),
+    "SLIMGPU_MatrixDevice": (C.c_int32, [C.c_void_p]),
     "SLIMGPU_MatrixGramBuildRows": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
     "SLIMGPU_MatrixGramView": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                            C.POINTER(C.c_int32)]),

@@ -43,6 +43,16 @@
 #ifndef SLIM_GRAMR_PROF
 #define SLIM_GRAMR_PROF 0
 #endif
+#ifndef SLIM_GRAMR_FROM_PLANES  // (A/B: 0 = aTy of a problem from the float G, as in round 5)
+#define SLIM_GRAMR_FROM_PLANES 1
+#endif
+// (A/B: 1 = the head of the likely next mover's row is pulled into L2 behind every row's head.  Measured
+// round 6, profiles/r06/prefetch_ab.txt: 2.93 s against 2.79 s without -- the row start is not waiting
+// for a cold L2 line, and the extra request and the candidate's ballot / readlane cost more than they
+// bring.  Off.)
+#ifndef SLIM_GRAMR_PREFETCH
+#define SLIM_GRAMR_PREFETCH 0
+#endif
 #ifndef SLIM_GRAMR_LATE_GATHERS  // (A/B: 0 = the gathers in front of the row's head, as in round 5)
 #define SLIM_GRAMR_LATE_GATHERS 1
 #endif
@@ -195,7 +205,9 @@ constexpr int gramr_ring_bytes(int ah) { return (kGramrNT / 64) * (ah + 2) * 102
 // Behind the ring, per wavefront: two buffers of 1280 bytes for the batch headers (x and the row
 // record of the 64 items of a batch), filled by LDS-DMA one batch ahead.
 constexpr int kGramrHdr = 1280;
-constexpr int gramr_hdr_bytes() { return (kGramrNT / 64) * 2 * kGramrHdr; }
+// (+ 256 bytes per wavefront: where the prefetch of the likely next row's head lands -- never read)
+constexpr int kGramrDump = SLIM_GRAMR_PREFETCH ? 256 : 0;
+constexpr int gramr_hdr_bytes() { return (kGramrNT / 64) * (2 * kGramrHdr + kGramrDump); }
 
 template <int KR, int KL, bool DMA = false, int WPS = ((KR <= 2 && KL == 0) ? 4 : 2), int AH = 2>
 __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
@@ -218,13 +230,19 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
   const int lane = tid & 63;
   const int wave = uni(tid >> 6);
   const int ncols = A.ncols;
+#if !SLIM_GRAMR_FROM_PLANES
   const int n4 = S.ncols_pad >> 2;
+#endif
   const int nchunks = P.nchunks;
   const float l1 = S.l1, l2 = S.l2;
+#if !SLIM_GRAMR_FROM_PLANES
   const float* __restrict__ Gm = S.G;  // floats: aTy of a problem (x init, active set)
   const int64_t ld = S.G_ld;
+#endif
   float* const x = S.xslab + (int64_t)blockIdx.x * S.x_stride;  // [ncols_pad], item ids, -inf = inactive
+#if !SLIM_GRAMR_FROM_PLANES
   float4* const x4 = reinterpret_cast<float4*>(x);
+#endif
   float4* const gl4 = reinterpret_cast<float4*>(g_lds);
   const int64_t* __restrict__ colptr = A.colptr;
 
@@ -249,12 +267,14 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
   unsigned long long* const pt_mark_p = &pt_mark_v;
 #endif
   char* const hdr_w = reinterpret_cast<char*>(g_lds) + KL * kPackGroup * 4 + (DMA ? gramr_ring_bytes(AH) : 0) +
-                      wave * (2 * kGramrHdr);
+                      wave * (2 * kGramrHdr + kGramrDump);
+  char* const dump_w = hdr_w + 2 * kGramrHdr;
   // (rg: the rank whose entry of this row every lane gathers -- its own visit's; gq: the four bytes)
   auto apply = [&](const uint8_t* __restrict__ plo, const uint8_t* __restrict__ phi,
                    const uint8_t* __restrict__ ph2, const uint8_t* __restrict__ pbase, const int hk,
                    const int h2k, const int cdiag, const int ediag, const float vdiag,
-                   const float nd, const int rg, uint32_t (&gq)[4]) __attribute__((always_inline)) {
+                   const float nd, const int rg, uint32_t (&gq)[4],
+                   const uint8_t* __restrict__ plo_next) __attribute__((always_inline)) {
     const bool gin1 = rg < hk * kPackGroup, gin2 = rg < h2k * kPackGroup;
     auto gathers = [&]() __attribute__((always_inline)) {
       // relaxed atomic loads of wavefront scope: ordinary global_load_ubyte in the ISA, but they stay
@@ -370,8 +390,18 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       static_for<(kGramrAhead < K ? kGramrAhead : K)>([&](auto kc) __attribute__((always_inline)) { request(kc); });
       // (round 6) the lanes' four byte gathers BEHIND the ring's first requests: in front of them they
       // were older than group 0, whose wait then waited for four scattered single-byte loads too
-      constexpr int kLate = SLIM_GRAMR_LATE_GATHERS ? 4 : 0;
+      constexpr int kLate = (SLIM_GRAMR_LATE_GATHERS ? 4 : 0) + (SLIM_GRAMR_PREFETCH ? 1 : 0);
       if constexpr (SLIM_GRAMR_LATE_GATHERS) gathers();
+      if constexpr (SLIM_GRAMR_PREFETCH) {
+        // (round 6) the first AH groups of the row the NEXT update will most likely stream -- the next
+        // pending visit whose coefficient is not 0 -- are pulled into L2 now, in the shadow of this row:
+        // what this wavefront will ask for there is AH x 1 KB = AH x 8 lines, one line per lane of one
+        // 4-byte LDS-DMA request into a slot nobody reads.  One operation, always issued (no candidate:
+        // this row's own head, lines already in flight) -- the wait counts below include it.
+        const int ln = lane < 8 * kGramrAhead ? lane : 0;
+        const uint32_t po = min((uint32_t)(kPackGroup * (ln >> 3)) + 1024u * (uint32_t)wave + 128u * (uint32_t)(ln & 7), vlast);
+        __builtin_amdgcn_global_load_lds(plo_next + po, dump_w, 4, 0, 0);
+      }
       static_for<K>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         if constexpr (k + kGramrAhead < K) request(std::integral_constant<int, k + kGramrAhead>{});
@@ -492,8 +522,62 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     const uint32_t gkey = (uint32_t)(grp * S.shard_count + S.shard_index);
     const int* __restrict__ ul = S.ulist + (int64_t)grp * S.u_stride;
     const int nunion = uni(S.tile_nunion[grp]);
+#if SLIM_GRAMR_FROM_PLANES
+    uint4 irec;
+    {
+      const uint4 mr = P.meta[item];
+      irec = make_uint4(uni(mr.x), uni(mr.y), uni(mr.z), uni(mr.w));
+    }
+#endif
+#if !SLIM_GRAMR_FROM_PLANES
     const float* __restrict__ arow = Gm + (int64_t)item * ld;  // aTy of this problem (floats, item ids)
+#endif
 
+#if SLIM_GRAMR_FROM_PLANES
+    // -- x = 0 on the active set {i != iC : aTy_i > l1} (estimate.c:433-444), -inf elsewhere.  aTy is
+    //    row iC of G: decoded here from the byte planes (the floats the unpacked G holds, exactly),
+    //    rank by rank, and stored by item id (item_of: ranks -> ids).  The float G is not read by this
+    //    kernel any more (round 6): a handle that can pack G drops its 4 ncols^2 bytes of floats.
+    {
+      const int hk0 = (int)((irec.x >> 17) & 15u), h2k0 = (int)((irec.x >> 21) & 15u);
+      const uint8_t* __restrict__ plo0 = P.lo + (int64_t)item * P.ldb;
+      const uint8_t* __restrict__ phi0 = P.hi + (int64_t)irec.y * kPackGroup;
+      const uint8_t* __restrict__ ph20 = phi0 + (int64_t)hk0 * kPackGroup;
+      const uint8_t* __restrict__ pb0 = P.base + (int64_t)item * kPackGroup;
+      int na = 0;
+      int64_t dact = 0;
+      for (int c = tid; c < nchunks; c += NT) {
+        const int kg = c / NT;
+        float f[16];
+        unpack16(*reinterpret_cast<const uint4*>(plo0 + 16 * (int64_t)c), f);
+        const float bf = 16.0f * (float)pb0[(c & (NT - 1)) * 16 + kg];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) f[e] += bf;
+        if (kg < hk0) unpack16_add(*reinterpret_cast<const uint4*>(phi0 + 16 * (int64_t)c), 256.0f, f);
+        if (kg < h2k0) unpack16_add(*reinterpret_cast<const uint4*>(ph20 + 16 * (int64_t)c), 65536.0f, f);
+        const int4* __restrict__ io = reinterpret_cast<const int4*>(P.item_of + 16 * (int64_t)c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int4 q = io[j];
+          const int it[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (it[u] >= 0) {
+              const bool act = it[u] != item && f[4 * j + u] > l1;   // (the diagonal's filler is never looked at)
+              x[it[u]] = act ? 0.0f : kInactive;
+              if (act) {
+                ++na;
+                dact += (int64_t)P.meta[it[u]].z;  // (SURVEY 8(d)'s D: every sweep visits the whole active set)
+              }
+            }
+          }
+        }
+      }
+      na = (int)wave_sum((float)na);  // (< 2^24: exact)
+      if (lane == 0 && na) atomicAdd(&s_na, na);
+      if (dact) atomicAdd(&s_D, (unsigned long long)dact);
+    }
+#else
     // -- x = 0 on the active set {i != iC : aTy_i > l1} (estimate.c:433-444), -inf elsewhere
     {
       const float4* __restrict__ a4 = reinterpret_cast<const float4*>(arow);
@@ -525,21 +609,25 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       if (lane == 0 && na) atomicAdd(&s_na, na);
       if (dact) atomicAdd(&s_D, (unsigned long long)dact);
     }
+#endif
     // -- warm start (estimate.c:453-464): previous coefficients of the coordinates active now (a
     //    negative value ends up 0 there: the flag-clearing loop resets every x < 0)
     int64_t fe = 0, we = 0;  // entries of the previous column still to fold
-    if (S.icolptr != nullptr && item < S.incols) {
-      __syncthreads();
-      fe = uni(S.icolptr[item]);
-      we = uni(S.icolptr[item + 1]);
-      for (int64_t e = fe + tid; e < we; e += NT) {
-        const int k = S.icolind[e];
-        if (k < ncols && tile_active(x[k])) {
-          const float v = S.icolval[e];
-          x[k] = v < 0.0f ? 0.0f : v;
+    auto warm_x = [&]() __attribute__((always_inline)) {
+      if (S.icolptr != nullptr && item < S.incols) {
+        __syncthreads();
+        fe = uni(S.icolptr[item]);
+        we = uni(S.icolptr[item + 1]);
+        for (int64_t e = fe + tid; e < we; e += NT) {
+          const int k = S.icolind[e];
+          if (k < ncols && tile_active(x[k])) {
+            const float v = S.icolval[e];
+            x[k] = v < 0.0f ? 0.0f : v;
+          }
         }
       }
-    }
+    };
+    warm_x();
     static_for<KRA>([&](auto kc) __attribute__((always_inline)) {
       gramr_reg<decltype(kc)::value>(gr) = (gramr_v16)(0.0f);
     });
@@ -743,7 +831,13 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
 #if SLIM_GRAMR_PROF
         pt_mark_v = pt_mark;
 #endif
-        apply(plo, phi, ph2, pbase, hk, h2k, rdiag >> 4, rdiag & 15, __uint_as_float(rec.w), nd, r, gq);  // (the one site that updates g)
+        // the likely next mover: the next pending visit with a coefficient (a zero one rarely moves)
+        const uint8_t* __restrict__ plo_next = plo;
+        if (SLIM_GRAMR_PREFETCH && phase == 1) {
+          const uint64_t cand = __ballot(part && xi != 0.0f) & pend;
+          if (cand) plo_next = P.lo + (int64_t)lane_bcast(i, __builtin_ctzll(cand)) * P.ldb;
+        }
+        apply(plo, phi, ph2, pbase, hk, h2k, rdiag >> 4, rdiag & 15, __uint_as_float(rec.w), nd, r, gq, plo_next);  // (the one site that updates g)
         float gsel = (float)gq[0] + 16.0f * (float)gq[3];
         gsel = in1 ? fmaf(256.0f, (float)gq[1], gsel) : gsel;
         gsel = in2 ? fmaf(65536.0f, (float)gq[2], gsel) : gsel;
@@ -771,7 +865,23 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         }
       } else if (phase == 2) {
         if (keep) {
+#if SLIM_GRAMR_FROM_PLANES
+          float aty = 0.0f;
+          if (wave == 0) {  // (row iC's entry at the lane's rank: the four bytes of a gather)
+            const int hk0 = (int)((irec.x >> 17) & 15u), h2k0 = (int)((irec.x >> 21) & 15u);
+            const uint8_t* __restrict__ plo0 = P.lo + (int64_t)item * P.ldb;
+            const uint8_t* __restrict__ phi0 = P.hi + (int64_t)irec.y * kPackGroup;
+            const uint8_t* __restrict__ ph20 = phi0 + (int64_t)hk0 * kPackGroup;
+            const uint8_t* __restrict__ pb0 = P.base + (int64_t)item * kPackGroup;
+            const bool j1 = r < hk0 * kPackGroup, j2 = r < h2k0 * kPackGroup;
+            aty = (float)plo0[r] + 16.0f * (float)pb0[((r >> 4) & (NT - 1)) * 16 + (r >> 13)];
+            if (j1) aty = fmaf(256.0f, (float)phi0[r], aty);
+            if (j2) aty = fmaf(65536.0f, (float)ph20[r], aty);
+          }
+          if (wave == 0) s_e2[lane] += (double)xi * ((double)aty + (double)g0);
+#else
           if (wave == 0) s_e2[lane] += (double)xi * ((double)arow[i] + (double)g0);
+#endif
           if (fits && wave == 0) {
             const int64_t dst = (int64_t)off + wpos + __popcll(mkeep & ((1ull << lane) - 1ull));
             S.out_ind[dst] = i;
@@ -866,5 +976,86 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     __syncthreads();
   }
 }
+
+// Union of the active sets of every tile (32 consecutive entries of the work list), ascending by
+// item id: cd_gram.hpp's gram_union_kernel read off the BYTE PLANES (round 6: the floats of G are
+// dropped once the planes stand).  One workgroup per tile: every row iC of the tile is decoded rank
+// by rank with coalesced 16-byte loads (the floats the unpacked G holds, exactly -- the same set as
+// the float kernel's), an active entry sets the bit of its ITEM in an LDS bitmap, and the bitmap is
+// written out in ascending order.  3.7 MB of planes per tile on the 100 000-item matrix instead of
+// 12.8 MB of floats.
+constexpr int kGramrUnionNT = 256;
+#ifdef SLIM_GRAM_PACK_KERNELS  // (defined by the one translation unit that owns the non-template kernels)
+__global__ __launch_bounds__(kGramrUnionNT) void gramr_union_kernel(const DevMatrix A, const SolveArgs S,
+                                                                     const GramPacked P) {
+  constexpr int NT = kGramrUnionNT;
+  constexpr int kWords = kGramrMaxGroups * kPackGroup / 32;  // items the largest instantiation holds
+  __shared__ uint32_t s_bits[kWords];
+  __shared__ int s_scan[NT];
+  const int tid = threadIdx.x;
+  const int grp = blockIdx.x;
+  const int base = grp * 32;
+  const int nprob = (S.nwork - base) < 32 ? (S.nwork - base) : 32;
+  const int ncols = A.ncols;
+  const int nwords = (ncols + 31) >> 5;
+  const int nchunks = P.nchunks;
+  int* __restrict__ ul = S.ulist + (int64_t)grp * S.u_stride;
+  for (int w = tid; w < nwords; w += NT) s_bits[w] = 0u;
+  __syncthreads();
+  for (int q = 0; q < nprob; ++q) {
+    const int it0 = uni(S.order[base + q]);
+    const uint4 mr = P.meta[it0];
+    const uint32_t rx = uni(mr.x), ry = uni(mr.y);
+    const int hk = (int)((rx >> 17) & 15u), h2k = (int)((rx >> 21) & 15u);
+    const uint8_t* __restrict__ plo = P.lo + (int64_t)it0 * P.ldb;
+    const uint8_t* __restrict__ phi = P.hi + (int64_t)ry * kPackGroup;
+    const uint8_t* __restrict__ ph2 = phi + (int64_t)hk * kPackGroup;
+    const uint8_t* __restrict__ pb = P.base + (int64_t)it0 * kPackGroup;
+    for (int c = tid; c < nchunks; c += NT) {
+      const int kg = c / kGramrNT;
+      float f[16];
+      unpack16(*reinterpret_cast<const uint4*>(plo + 16 * (int64_t)c), f);
+      const float bf = 16.0f * (float)pb[(c & (kGramrNT - 1)) * 16 + kg];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) f[e] += bf;
+      if (kg < hk) unpack16_add(*reinterpret_cast<const uint4*>(phi + 16 * (int64_t)c), 256.0f, f);
+      if (kg < h2k) unpack16_add(*reinterpret_cast<const uint4*>(ph2 + 16 * (int64_t)c), 65536.0f, f);
+      const int4* __restrict__ io = reinterpret_cast<const int4*>(P.item_of + 16 * (int64_t)c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int4 qv = io[j];
+        const int it[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (it[u] >= 0 && it[u] != it0 && f[4 * j + u] > S.l1) atomicOr(&s_bits[it[u] >> 5], 1u << (it[u] & 31));
+      }
+    }
+  }
+  __syncthreads();
+  // ascending: thread t owns the words [t W, (t + 1) W)
+  const int W = (nwords + NT - 1) / NT;
+  const int w0 = tid * W, w1 = min(nwords, w0 + W);
+  int cnt = 0;
+  for (int w = w0; w < w1; ++w) cnt += __popc(s_bits[w]);
+  s_scan[tid] = cnt;
+  __syncthreads();
+  for (int o = 1; o < NT; o <<= 1) {  // (inclusive scan over the 256 counts)
+    const int v = tid >= o ? s_scan[tid - o] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  int pos = s_scan[tid] - cnt;
+  for (int w = w0; w < w1; ++w) {
+    uint32_t b = s_bits[w];
+    while (b) {
+      const int j = __builtin_ctz(b);
+      b &= b - 1u;
+      ul[pos++] = (w << 5) + j;
+    }
+  }
+  if (tid == NT - 1) S.tile_nunion[grp] = s_scan[tid];
+}
+#endif  // SLIM_GRAM_PACK_KERNELS
 
 }  // namespace slimamd

@@ -83,6 +83,7 @@ struct slimgpu_matrix {
   int64_t Gp_ldb = 0;
   int32_t Gp_nchunks = 0;
   bool Gp_ready = false, Gp_tried = false;
+  bool Gf_dropped = false;          // the floats of G were freed once the planes stood (drop_float_gram)
   double Gp_bytes_per_row = 0;      // average bytes of a packed row (lo + hi + hi2)
   int expect_solves = 0;            // announced by the caller (model-selection grids)
   std::vector<int32_t> last_order;  // work list of the most recent solve
@@ -777,7 +778,7 @@ const std::vector<slimgpu_matrix_t*>& matrix_replicas(const slimgpu_matrix_t* m)
   return m->replicas;
 }
 void matrix_adopt_csr(slimgpu_matrix_t* m) { m->owns_csr = true; }
-int32_t matrix_device(const slimgpu_matrix_t* m) { return m->device; }
+int32_t matrix_device(const slimgpu_matrix_t* m) { return m ? m->device : -1; }
 void matrix_set_setup_ms(slimgpu_matrix_t* m, double ms) { m->setup_ms = ms; }
 
 int32_t matrix_info(const slimgpu_matrix_t* m, int32_t* nrows, int32_t* ncols, int64_t* nnz) {
@@ -947,6 +948,24 @@ bool pack_gram(slimgpu_matrix* m) {
   return true;
 }
 
+// Once the byte planes stand and a kernel can consume them, nothing reads the floats of G: the
+// on-chip kernel takes aTy of a problem (x's active set, the loss term) from the planes of row iC
+// (cd_gramr.hpp, SLIM_GRAMR_FROM_PLANES).  Large ones are freed -- C4: 40 GB per handle --; a later
+// solve that needs floats (SLIM_GPU_NO_GRAMR=1, SLIMGPU_MatrixGramView) forms them again.
+// SLIM_GPU_KEEP_G=1 keeps them; SLIM_GPU_DROP_G_MIN_GB sets the size from which they go (default 8).
+void drop_float_gram(slimgpu_matrix* m) {
+  if (!m->Gp_ready || !m->ws_G.p || std::getenv("SLIM_GPU_KEEP_G") || std::getenv("SLIM_GPU_NO_GRAMR")) return;
+  if ((m->Gp_nchunks + kGramrNT - 1) / kGramrNT > kGramrMaxGroups) return;
+  double min_gb = 8.0;
+  if (const char* e = std::getenv("SLIM_GPU_DROP_G_MIN_GB")) min_gb = std::atof(e);
+  if ((double)m->ws_G.bytes < min_gb * 1073741824.0) return;
+  (void)hipStreamSynchronize(m->stream);
+  (void)hipFree(m->ws_G.p);
+  m->ws_G.p = nullptr;
+  m->ws_G.bytes = 0;
+  m->Gf_dropped = true;
+}
+
 }  // namespace
 
 slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
@@ -1080,6 +1099,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       }
     }
     if (use_gram) kernel = SLIMGPU_KERNEL_GRAM;
+    if (use_gram && m->G_ready && m->Gf_dropped && std::getenv("SLIM_GPU_NO_GRAMR")) {
+      m->G_ready = false;  // (the float kernels were asked for: form the floats again; the planes stay)
+      m->Gf_dropped = false;
+    }
     if (use_gram && !m->G_ready) {
       // G by the tile kernel's screen pass over every column (S.gram_mode 3), once per handle
       const double tb = now_ms();
@@ -1106,9 +1129,12 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       const double t_sums = now_ms();
       const double sums_kernel_ms = last_stats().kernel_ms;
       m->G_ready = true;
-      m->Gp_ready = false;
-      m->Gp_tried = false;
-      if (!pack_gram(m)) m->Gp_ready = false;
+      m->Gf_dropped = false;
+      if (!m->Gp_ready) {  // (planes of an earlier build of the same G are still right)
+        m->Gp_tried = false;
+        if (!pack_gram(m)) m->Gp_ready = false;
+      }
+      drop_float_gram(m);
       m->G_build_ms = now_ms() - tb;
       m->G_alloc_ms = t_alloc - tb;
       m->G_sums_ms = t_sums - t_alloc;
@@ -1136,7 +1162,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     // the items fit the largest instantiation (106 496); SLIM_GPU_NO_GRAMR=1: the float kernels
     GramrFn fn_r = nullptr;
     int gramr_kr = 0, gramr_kl = 0;
-    if (use_gram && m->G_ready && !m->Gp_tried) (void)pack_gram(m);
+    if (use_gram && m->G_ready && !m->Gp_tried && !m->Gf_dropped) {
+      (void)pack_gram(m);
+      drop_float_gram(m);
+    }
     size_t gramr_lds = 0;
     // rows through the LDS ring (global_load_lds) where a row is many groups long -- measured
     // (profiles/r05/gramr_dma_ab.txt): C4, 13 groups, kernel 6.62 -> 5.37 s; C5, 3 groups, where
@@ -1147,6 +1176,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     if (use_gram && m->Gp_ready && !std::getenv("SLIM_GPU_NO_GRAMR"))
       fn_r = gramr_kernel(m->Gp_nchunks, gramr_dma, &gramr_kr, &gramr_kl, &gramr_lds);
     const bool use_gramr = fn_r != nullptr;
+    if (use_gram && !use_gramr && m->Gf_dropped) {
+      set_error("SLIMGPU_Learn: the floats of G were dropped and the byte-plane kernel cannot run this solve");
+      return fail(SLIM_ERROR);
+    }
     if (use_gramr) {
       gram_nw = kGramrNT / 64;
       gram_v = 1;  // (x only in the slab: g is on chip)
@@ -1567,7 +1600,7 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       // the fallback another geometry)
       S.gram_mode = (attempt == 0 && !cluster_fallback) ? gram_mode : 0;
       S.gram = d_gram;
-      S.G = static_cast<float*>(m->ws_G.p);
+      S.G = static_cast<float*>(m->ws_G.p);  // (nullptr once dropped: only the float kernels read it)
       S.G_ld = m->G_ld;
       S.tile_nunion = d_nunion;
       S.gram_pos = nullptr;
@@ -1630,7 +1663,27 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
           use_tile ? std::max(1, std::min((npend + tileP - 1) / tileP, nclusters)) * clusterK
                    : std::max(1, std::min(npend, nwaves));
       HIP_TRY(hipEventRecord(ev0, stream));
-      if (use_gram)  // the union of the active sets of every tile, read off G (inside kernel_ms)
+      GramPacked P{};
+      if (use_gramr) {
+        P.lo = static_cast<const uint8_t*>(m->ws_Glo.p);
+        P.ldb = m->Gp_ldb;
+        P.hi = static_cast<const uint8_t*>(m->ws_Ghi.p);
+        P.hi_off = static_cast<const int64_t*>(m->ws_hioff.p);
+        P.hi_k = static_cast<const int32_t*>(m->ws_hik.p);
+        P.hi2_off = static_cast<const int64_t*>(m->ws_hi2off.p);
+        P.hi2_k = static_cast<const int32_t*>(m->ws_hi2k.p);
+        P.base = static_cast<const uint8_t*>(m->ws_Gbase.p);
+        P.diag = static_cast<const float*>(m->ws_Gdiag.p);
+        P.meta = static_cast<const uint4*>(m->ws_Gmeta.p);
+        P.rank_of = static_cast<const int32_t*>(m->ws_rankof.p);
+        P.item_of = static_cast<const int32_t*>(m->ws_itemof.p);
+        P.nchunks = m->Gp_nchunks;
+      }
+      // the union of the active sets of every tile, read off G (inside kernel_ms): off the byte
+      // planes when the packed solver runs (the floats may be gone: drop_float_gram)
+      if (use_gramr)
+        hipLaunchKernelGGL(gramr_union_fn(), dim3(S.ngroups), dim3(gramr_union_threads()), 0, stream, A, S, P);
+      else if (use_gram)
         hipLaunchKernelGGL(gram_union_fn(), dim3(S.ngroups), dim3(64), 0, stream, A, S);
       // the heavy phase needs at least one whole big cluster in the launch
       if (S.nheavy > 0 && launch_waves < clusterHi) S.nheavy = 0;
@@ -1655,20 +1708,6 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
         if (const char* e = std::getenv("SLIM_GPU_XCD")) S.xcd_swizzle = std::atoi(e) != 0;
       }
       if (use_gramr) {
-        GramPacked P;
-        P.lo = static_cast<const uint8_t*>(m->ws_Glo.p);
-        P.ldb = m->Gp_ldb;
-        P.hi = static_cast<const uint8_t*>(m->ws_Ghi.p);
-        P.hi_off = static_cast<const int64_t*>(m->ws_hioff.p);
-        P.hi_k = static_cast<const int32_t*>(m->ws_hik.p);
-        P.hi2_off = static_cast<const int64_t*>(m->ws_hi2off.p);
-        P.hi2_k = static_cast<const int32_t*>(m->ws_hi2k.p);
-        P.base = static_cast<const uint8_t*>(m->ws_Gbase.p);
-        P.diag = static_cast<const float*>(m->ws_Gdiag.p);
-        P.meta = static_cast<const uint4*>(m->ws_Gmeta.p);
-        P.rank_of = static_cast<const int32_t*>(m->ws_rankof.p);
-        P.item_of = static_cast<const int32_t*>(m->ws_itemof.p);
-        P.nchunks = m->Gp_nchunks;
         hipLaunchKernelGGL(fn_r, dim3(launch_now), dim3(kGramrNT), gram_lds, stream, A, S, P);
       } else
       hipLaunchKernelGGL(fn, dim3(launch_now),
@@ -2020,7 +2059,9 @@ int32_t gram_commit(slimgpu_matrix_t* m) {
     m->G_ready = true;
     m->Gp_ready = false;
     m->Gp_tried = false;
+    m->Gf_dropped = false;
     (void)pack_gram(m);  // (false: G is not integer-valued or the planes do not fit -- float kernels)
+    drop_float_gram(m);
     return SLIM_OK;
   } catch (const HipError& e) {
     report(e, "SLIMGPU_MatrixGramCommit");

@@ -30,6 +30,8 @@ GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes)
   *lds_bytes = sizeof(float) * (size_t)*kl * kPackGroup + (dma ? (size_t)gramr_ring_bytes(ring_ah) : 0) + (size_t)gramr_hdr_bytes();
   return fn;
 }
+GramrFn gramr_union_fn() { return gramr_union_kernel; }
+int gramr_union_threads() { return kGramrUnionNT; }
 PackScanFn gram_pack_scan_fn() { return gram_pack_scan; }
 PackWriteFn gram_pack_write_fn() { return gram_pack_write; }
 PackMetaFn gram_pack_meta_fn() { return gram_pack_meta; }

@@ -15,6 +15,10 @@ using GramrFn = void (*)(const DevMatrix, const SolveArgs, const GramPacked);
 GramrFn gramr_kernel(int nchunks, bool dma, int* kr, int* kl, size_t* lds_bytes);
 GramrFn gramr_kernel_k13(bool* dma, int* ring_ah);  // <10, 3>: its own translation unit (compiles beside the others)
 
+// the tiles' union lists read off the byte planes (cd_gramr.hpp: gramr_union_kernel; kGramrUnionNT threads per tile)
+GramrFn gramr_union_fn();
+int gramr_union_threads();
+
 using PackScanFn = void (*)(const float*, int64_t, int, const int32_t*, int, int, int32_t*, int32_t*, int32_t*);
 using PackWriteFn = void (*)(const float*, int64_t, int, const int32_t*, int, uint8_t*, int64_t, uint8_t*,
                              const int64_t*, const int32_t*, uint8_t*, const int64_t*, const int32_t*, uint8_t*, float*);

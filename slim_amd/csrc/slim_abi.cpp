@@ -408,6 +408,8 @@ void SLIMGPU_MatrixExpectSolves(slimgpu_matrix_t* mat, int32_t nsolves) {
   matrix_expect_solves(mat, nsolves);
 }
 
+int32_t SLIMGPU_MatrixDevice(const slimgpu_matrix_t* mat) { return matrix_device(mat); }
+
 int32_t SLIMGPU_MatrixGramBuildRows(slimgpu_matrix_t* mat, int32_t row_begin, int32_t row_end) {
   set_error("");
   return gram_build_rows(mat, row_begin, row_end);

@@ -92,6 +92,7 @@ class DeviceMatrix(object):
         nr, nc, nz = C.c_int32(), C.c_int32(), C.c_int64()
         self._lib.SLIMGPU_MatrixInfo(self.handle, C.byref(nr), C.byref(nc), C.byref(nz))
         self.nrows, self.ncols, self.nnz = nr.value, nc.value, nz.value
+        self.device = int(self._lib.SLIMGPU_MatrixDevice(self.handle))   # the HIP device of its buffers
 
     @classmethod
     def from_scipy(cls, R, binary=False, device=None):
