@@ -205,6 +205,27 @@ slim_t *SLIMGPU_LearnColumns(slimgpu_matrix_t *mat, int32_t ncolumns,
                              const int32_t *columns, int32_t *ioptions,
                              double *doptions, slim_t *imodel, int32_t *r_status);
 
+/* Models resident in HBM.  A model-selection grid (src/programs/slim_mselect.c:94-113,
+ * src/libslim/pyapi.c:283-300) learns its models one from the other over the same R: SLIM_Learn's
+ * host model (SaveModel, estimate.c:570-593) is then 1.2 GB that cross PCIe twice per pair -- down as
+ * the result, up again as the next pair's warm start.  SLIMGPU_LearnResident solves like
+ * SLIMGPU_Learn but leaves the model (both views, formed on the device) in HBM and takes the warm
+ * start from such a model without an upload; SLIMGPU_ModelFetch forms the host model of SLIM_Learn
+ * (the same arrays, bit for bit; SLIM_FreeModel releases it) when the caller wants it, and
+ * SLIMGPU_ModelFetchBegin starts that copy on its own stream and host thread so that it runs beside
+ * the next solve (ModelFetch then joins it).  One device per model (ngpus = 1). */
+typedef struct slimgpu_model slimgpu_model_t;
+slimgpu_model_t *SLIMGPU_LearnResident(slimgpu_matrix_t *mat, int32_t *ioptions, double *doptions,
+                                       const slimgpu_model_t *warm, int32_t *r_status);
+int64_t SLIMGPU_ModelNnz(const slimgpu_model_t *model);    /* -1: null */
+int32_t SLIMGPU_ModelFetchBegin(slimgpu_model_t *model);
+slim_t *SLIMGPU_ModelFetch(slimgpu_model_t *model, int32_t *r_status);
+void SLIMGPU_ModelFree(slimgpu_model_t **model);
+/* SLIMGPU_Predict through a resident model: its row view is read where it lies (lists and scores
+ * bit-identical to Py_SLIM_Predict on the fetched model).  1 <= nrcmds <= 128. */
+int32_t SLIMGPU_ModelPredict(int32_t nrcmds, const slimgpu_model_t *model, slim_t *trnhandle,
+                             int32_t *output, float *scores);
+
 /* Py_SLIM_Predict on the GPU (one wavefront per user; lists and scores are bit-identical
  * to the host scorer, ties included).  1 <= nrcmds <= 128.  Fails without a device. */
 int32_t SLIMGPU_Predict(int32_t nrcmds, slim_t *slimhandle, slim_t *trnhandle,

@@ -29,9 +29,13 @@ def main():
                     help="auto: the engine's choice (item-space CD once the grid is announced)")
     ap.add_argument("--no-announce", action="store_true",
                     help="do not tell the engine how many solves are coming (SLIMGPU_MatrixExpectSolves)")
+    ap.add_argument("--resident", default="", choices=["", "fetch", "nofetch"],
+                    help="models stay in HBM (SLIMGPU_LearnResident), each pair warm-started from the resident "
+                         "previous one; fetch: every model still reaches the host, copied beside the next solve")
     args = ap.parse_args()
     import torch
     from slim_amd import synth
+    from slim_amd import _lib as _l
     from slim_amd.engine import KERNEL_AUTO, KERNEL_GRAM, KERNEL_TILE, DeviceMatrix
 
     dev = torch.device("cuda", 0)
@@ -50,6 +54,44 @@ def main():
     prev = None
     out = []
     t_all = time.time()
+    if args.resident:
+        fetch = args.resident == "fetch"
+        fetched_nnz = []
+        for l1, l2 in pairs:
+            t0 = time.time()
+            cur, st = mat.learn_resident(warm=prev, l1r=l1, l2r=l2, optTol=1e-7, niters=10000, seed=args.seed,
+                                         col_begin=0, col_end=ce, kernel=kernel)
+            t1 = time.time()
+            if prev is not None:
+                if fetch:   # begun before this solve: the copy ran beside it
+                    h = prev.fetch(return_handle=True)
+                    v = C.cast(h, C.POINTER(_l.CsrView)).contents
+                    fetched_nnz.append(int(v.colptr[v.ncols]))
+                    mat._lib.SLIM_FreeModel(C.byref(C.c_void_p(h)))
+                prev.free()
+            if fetch:
+                cur.fetch_begin()
+            prev = cur
+            dt = time.time() - t0
+            rec = {"l1": l1, "l2": l2, "columns": ce, "wall_s": round(dt, 2), "solve_call_s": round(t1 - t0, 2),
+                   "kernel_s": round(st["kernel_ms"] * 1e-3, 2), "columns_per_s": round(ce / dt, 1),
+                   "nnzW": int(st["nnzW"]), "kernel": int(st["kernel"]),
+                   "gram_build_s": round(st["gram_build_ms"] * 1e-3, 2), "gather_s": round(st["gather_ms"] * 1e-3, 2),
+                   "warm": len(out) > 0, "resident": args.resident}
+            out.append(rec)
+            print(json.dumps(rec), flush=True)
+        t0 = time.time()
+        if fetch:
+            h = prev.fetch(return_handle=True)
+            v = C.cast(h, C.POINTER(_l.CsrView)).contents
+            fetched_nnz.append(int(v.colptr[v.ncols]))
+            mat._lib.SLIM_FreeModel(C.byref(C.c_void_p(h)))
+            assert fetched_nnz == [r["nnzW"] for r in out], "a fetched model does not have the solve's nnz"
+        prev.free()
+        print(json.dumps({"workload": args.workload, "nrows": nrows, "ncols": ncols, "nnz": int(rowind.numel()),
+                          "pairs": len(out), "resident": args.resident, "last_fetch_s": round(time.time() - t0, 2),
+                          "total_s": round(time.time() - t_all, 1)}))
+        return
     for l1, l2 in pairs:
         t0 = time.time()
         h, st = mat.learn(imodel=prev, return_handle=True, l1r=l1, l2r=l2, optTol=1e-7, niters=10000,

@@ -95,6 +95,13 @@ _SIGNATURES = {
     "SLIMGPU_MatrixGramCommit": (C.c_int32, [C.c_void_p]),
     "SLIMGPU_Learn": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_int32)]),
+    "SLIMGPU_LearnResident": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_int32)]),
+    "SLIMGPU_ModelNnz": (C.c_int64, [C.c_void_p]),
+    "SLIMGPU_ModelFetchBegin": (C.c_int32, [C.c_void_p]),
+    "SLIMGPU_ModelFetch": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "SLIMGPU_ModelFree": (None, [C.POINTER(C.c_void_p)]),
+    "SLIMGPU_ModelPredict": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "SLIMGPU_LearnColumns": (C.c_void_p, [C.c_void_p, C.c_int32, i32_1d, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.POINTER(C.c_int32)]),
     "SLIMGPU_Predict": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, i32_1d, f32_1d]),

@@ -318,6 +318,7 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
     //    nnz of C4; this form is bound by the id stream)
     const bool gbits = !HAS_VAL && S.gram_mode == 3 && S.gram_bits != 0;
     if (gbits) {
+      const int gst = S.gram_split_stride;  // (K + 1, or the row length of the user passes' table)
       const int nus = uend - ubase;
       for (int k = tid; k < nus; k += NT) s_bits[k] = 0u;
       __syncthreads();
@@ -326,8 +327,8 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         const int pq = wave + pp * NW;
         const int witem = s_item[pq];
         if (witem >= 0) {
-          const int64_t cs = uni(csplit[(int64_t)witem * (K + 1) + mk]);
-          const int64_t ce = uni(csplit[(int64_t)witem * (K + 1) + mk + 1]);
+          const int64_t cs = uni(csplit[(int64_t)witem * gst + mk]);
+          const int64_t ce = uni(csplit[(int64_t)witem * gst + mk + 1]);
           for (int64_t j = cs + lane; j < ce; j += 64) atomicOr(&s_bits[ci[j] - ubase], 1u << pq);
         }
       }
@@ -352,8 +353,8 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
           const int i = have ? ord[pl] : 0;
           int64_t cs = 0, ce = 0;
           if (have) {
-            cs = csplit[(int64_t)i * (K + 1) + mk];
-            ce = csplit[(int64_t)i * (K + 1) + mk + 1];
+            cs = csplit[(int64_t)i * gst + mk];
+            ce = csplit[(int64_t)i * gst + mk + 1];
           }
           const int len = (int)(ce - cs);
           uint32_t ones = 0u, twos = 0u, fours = 0u, hi[NPL - 3];
@@ -436,16 +437,16 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
       int64_t cs_n = 0, ce_n = 0;
       int pos_n = 0;
       if (wave < ncols) {
-        cs_n = csplit[(int64_t)wave * (K + 1) + mk];
-        ce_n = csplit[(int64_t)wave * (K + 1) + mk + 1];
+        cs_n = csplit[(int64_t)wave * gst + mk];
+        ce_n = csplit[(int64_t)wave * gst + mk + 1];
         pos_n = S.gram_pos[wave];
       }
       for (int i = wave; i < ncols; i += NW) {
         const int64_t cs = uni(cs_n), ce = uni(ce_n);
         const int pos_i = uni(pos_n);
         if (i + NW < ncols) {
-          cs_n = csplit[(int64_t)(i + NW) * (K + 1) + mk];
-          ce_n = csplit[(int64_t)(i + NW) * (K + 1) + mk + 1];
+          cs_n = csplit[(int64_t)(i + NW) * gst + mk];
+          ce_n = csplit[(int64_t)(i + NW) * gst + mk + 1];
           pos_n = S.gram_pos[i + NW];
         }
         if (pos_i < base) continue;  // (symmetric fill: see the screen pass)
@@ -693,6 +694,9 @@ __device__ __forceinline__ bool tile_phase(const DevMatrix& A, const SolveArgs& 
         if (pi >= base && it >= 0) {
           float a = 0.0f;  // members in rank order
           for (int k = 0; k < K; ++k) a += S.atypart[(int64_t)(cid * K + k) * S.x_stride + idx];
+          // (user passes: every pass holds the sums over ITS users; counts are integers below 2^24,
+          // so the float additions are exact in any order)
+          if (S.gram_accum) a += S.G[(int64_t)it * S.G_ld + i];
           S.G[(int64_t)it * S.G_ld + i] = a;
           if (pi >= base + P) S.G[(int64_t)i * S.G_ld + it] = a;
         }

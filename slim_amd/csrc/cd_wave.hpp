@@ -116,6 +116,10 @@ struct SolveArgs {
   int32_t* tile_nunion;
   const int32_t* gram_pos;       // gram_mode 3: position of every column in the work list
   int32_t gram_bits;             // gram_mode 3, binary matrix: y packed one word per user in LDS
+  int32_t gram_split_stride;     // gram_bits: entries per column of the slice table the member reads (K + 1; with
+                                 // user passes, the passes' common table: the launch's ubounds / csplit point at
+                                 // the pass's first range)
+  int32_t gram_accum;            // gram_bits, user passes after the first: the sums are ADDED to G
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;
   int64_t* out_off;

@@ -19,7 +19,9 @@
 #include <mutex>
 #include <new>
 #include <numeric>
+#include <memory>
 #include <string>
+#include <thread>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -56,6 +58,12 @@ struct slimgpu_matrix {
   int32_t* d_ubounds[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int64_t* d_csplit[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int32_t max_range_rows[6] = {0, 0, 0, 0, 0, 0};
+  // the G builder's user passes (learn_cd, gram_passes): 32 * np user ranges of equal nnz and the
+  // slice boundaries of every column over them, [ncols][32 * np + 1]
+  int32_t* d_gubounds = nullptr;
+  int64_t* d_gcsplit = nullptr;
+  int gsplit_np = 0;
+  int32_t gsplit_max_rows = 0;
   double setup_ms = 0;
   int num_cus = 256;
   // workspace reused by successive solves
@@ -90,6 +98,28 @@ struct slimgpu_matrix {
   Buf ws_order, ws_cnt, ws_off, ws_stat_i, ws_stat_l, ws_stat_f, ws_misc, ws_arena_i, ws_arena_v,
       ws_slab, ws_xslab, ws_ulist, ws_trace, ws_mailbox, ws_part, ws_icolptr, ws_icolind,
       ws_icolval;
+  Buf ws_tkeys[2], ws_tpay[2], ws_ttmp;  // the row view of a resident model (transpose_on_device)
+};
+
+// A learned model resident in HBM (SLIMGPU_LearnResident): the column view as SaveModel lays it out
+// (estimate.c:570-593; ids ascending in every column) and the row view, formed on the device.
+struct slimgpu_model {
+  int device = 0;
+  int32_t n = 0;      // nrows = ncols of W
+  int64_t nnz = 0;
+  int64_t* d_colptr = nullptr;
+  int32_t* d_colind = nullptr;
+  float* d_colval = nullptr;
+  int64_t* d_rowptr = nullptr;
+  int32_t* d_rowind = nullptr;
+  float* d_rowval = nullptr;
+  // a fetch to the host running beside the next solve (model_fetch_begin)
+  std::thread fetcher;
+  bool fetch_begun = false;
+  slim_csr_t* fetched = nullptr;
+  int32_t fetch_status = 0;
+  std::string fetch_error;
+  double fetch_ms = 0;
 };
 
 namespace slimamd {
@@ -293,6 +323,22 @@ __global__ void k_col_split(int32_t ncols, int32_t K, const int32_t* __restrict_
   }
 }
 
+// one wavefront per column: the entries a launch left in its arena, into column order
+__global__ void k_gather_columns(int32_t ncols, const int64_t* __restrict__ colptr,
+                                 const int64_t* __restrict__ src_off, const int32_t* __restrict__ src_ind,
+                                 const float* __restrict__ src_val, int32_t* __restrict__ colind,
+                                 float* __restrict__ colval) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t c = wave; c < ncols; c += nwaves) {
+    const int64_t d = colptr[c], n = colptr[c + 1] - d, s = src_off[c];
+    for (int64_t k = lane; k < n; k += 64) {
+      colind[d + k] = src_ind[s + k];
+      colval[d + k] = src_val[s + k];
+    }
+  }
+}
 void drop_screen_cache(slimgpu_matrix* m) {
   if (m->ws_gram.p) (void)hipFree(m->ws_gram.p);
   m->ws_gram.p = nullptr;
@@ -420,6 +466,43 @@ void build_column_view(slimgpu_matrix* m) {
   m->nonpositive = (h_inexact & 2) != 0;
 }
 
+// The other view of a square sparse matrix held as (ptr, ind, val) with n rows, on the device: the
+// staging pass's own steps (key = id, payload = (source row << 32 | value), stable radix sort by key)
+// -- entries of a destination row keep the order of their source rows, i.e. ascending ids, the arrays
+// csr_build_index (host_csr.cpp) forms.  The outputs are allocated here; temporaries live with the handle.
+void transpose_on_device(slimgpu_matrix* m, int32_t n, int64_t nnz, const int64_t* d_ptr,
+                         const int32_t* d_ind, const float* d_val, int64_t** o_ptr, int32_t** o_ind,
+                         float** o_val) {
+  hipStream_t st = m->stream;
+  *o_ptr = dev_alloc<int64_t>((size_t)n + 1);
+  *o_ind = dev_alloc<int32_t>((size_t)std::max<int64_t>(nnz, 1));
+  *o_val = dev_alloc<float>((size_t)std::max<int64_t>(nnz, 1));
+  if (nnz <= 0) {
+    HIP_TRY(hipMemsetAsync(*o_ptr, 0, sizeof(int64_t) * ((size_t)n + 1), st));
+    return;
+  }
+  if (nnz > 0xFFFFFFF0ll) throw HipError{hipErrorInvalidValue, "model nnz >= 2^32 not supported"};
+  uint32_t* keys_in = ws_get<uint32_t>(m->ws_tkeys[0], (size_t)nnz, m);
+  uint32_t* keys_out = ws_get<uint32_t>(m->ws_tkeys[1], (size_t)nnz, m);
+  uint64_t* pay_in = ws_get<uint64_t>(m->ws_tpay[0], (size_t)nnz, m);
+  uint64_t* pay_out = ws_get<uint64_t>(m->ws_tpay[1], (size_t)nnz, m);
+  const int cap = m->num_cus * 16;
+  int32_t* d_flags = ws_get<int32_t>(m->ws_misc, 16, m);  // (the solver's scalars: read back already)
+  hipLaunchKernelGGL(k_pack_rows, dim3(grid_for((int64_t)n * 64, 256, cap)), dim3(256), 0, st, n, n, nnz, d_ptr,
+                     d_ind, d_val, keys_in, pay_in, d_flags);
+  HIP_TRY(hipGetLastError());
+  unsigned bits = 1;
+  while ((1ull << bits) < (unsigned long long)n) ++bits;
+  size_t tmp_bytes = 0;
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, pay_in, pay_out, (size_t)nnz, 0u, bits, st));
+  void* tmp = ws_get<uint8_t>(m->ws_ttmp, tmp_bytes ? tmp_bytes : 1, m);
+  HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, pay_in, pay_out, (size_t)nnz, 0u, bits, st));
+  hipLaunchKernelGGL(k_unpack_cols, dim3(grid_for(nnz, 256, cap)), dim3(256), 0, st, nnz, pay_out, *o_ind, *o_val);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_col_offsets, dim3(grid_for(nnz + 1, 256, cap)), dim3(256), 0, st, nnz, n, keys_out, *o_ptr);
+  HIP_TRY(hipGetLastError());
+}
+
 // user ranges of equal nnz + per-column slice boundaries for clusters of size K = 1 << lg
 void ensure_cluster_split(slimgpu_matrix* m, int lg) {
   if (m->d_csplit[lg]) return;
@@ -453,6 +536,40 @@ void ensure_cluster_split(slimgpu_matrix* m, int lg) {
   HIP_TRY(hipStreamSynchronize(m->stream));
 }
 
+// the same for the G builder's user passes: nr = 32 * np ranges (np passes of a cluster of 32)
+void ensure_gram_split(slimgpu_matrix* m, int np) {
+  if (m->gsplit_np == np && m->d_gcsplit) return;
+  (void)hipFree(m->d_gubounds);
+  (void)hipFree(m->d_gcsplit);
+  m->d_gubounds = nullptr;
+  m->d_gcsplit = nullptr;
+  m->gsplit_np = 0;
+  const int nr = 32 * np;
+  std::vector<int32_t> ub((size_t)nr + 1, 0);
+  ub[(size_t)nr] = m->nrows;
+  if (m->h_rowptr.empty()) {
+    m->h_rowptr.resize((size_t)m->nrows + 1);
+    HIP_TRY(hipMemcpy(m->h_rowptr.data(), m->d_rowptr, sizeof(int64_t) * ((size_t)m->nrows + 1),
+                      hipMemcpyDeviceToHost));
+  }
+  for (int j = 1; j < nr; ++j) {
+    const int64_t want = (int64_t)((double)m->nnz / nr * j);
+    ub[(size_t)j] = (int32_t)(std::lower_bound(m->h_rowptr.begin(), m->h_rowptr.end(), want) - m->h_rowptr.begin());
+    ub[(size_t)j] = std::min(std::max(ub[(size_t)j], ub[(size_t)j - 1]), m->nrows);
+  }
+  int32_t mx = 1;
+  for (int j = 0; j < nr; ++j) mx = std::max(mx, ub[(size_t)j + 1] - ub[(size_t)j]);
+  m->gsplit_max_rows = mx;
+  m->d_gubounds = dev_alloc<int32_t>((size_t)nr + 1);
+  HIP_TRY(hipMemcpy(m->d_gubounds, ub.data(), sizeof(int32_t) * ((size_t)nr + 1), hipMemcpyHostToDevice));
+  m->d_gcsplit = dev_alloc<int64_t>((size_t)m->ncols * ((size_t)nr + 1));
+  hipLaunchKernelGGL(k_col_split, dim3(grid_for((int64_t)m->ncols * (nr + 1), 256, m->num_cus * 8)), dim3(256), 0,
+                     m->stream, m->ncols, nr, m->d_gubounds, m->d_colptr, m->d_colind, m->d_gcsplit);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  m->gsplit_np = np;
+}
+
 void destroy(slimgpu_matrix* m) {
   if (!m) return;
   for (slimgpu_matrix* r : m->replicas) destroy(r);
@@ -472,12 +589,15 @@ void destroy(slimgpu_matrix* m) {
     (void)hipFree(m->d_ubounds[k]);
     (void)hipFree(m->d_csplit[k]);
   }
+  (void)hipFree(m->d_gubounds);
+  (void)hipFree(m->d_gcsplit);
   for (slimgpu_matrix::Buf* b :
        {&m->ws_order, &m->ws_cnt, &m->ws_off, &m->ws_stat_i, &m->ws_stat_l, &m->ws_stat_f,
         &m->ws_misc, &m->ws_arena_i, &m->ws_arena_v, &m->ws_slab, &m->ws_xslab, &m->ws_ulist,
         &m->ws_trace, &m->ws_mailbox, &m->ws_part, &m->ws_icolptr, &m->ws_icolind, &m->ws_icolval,
         &m->ws_gram, &m->ws_G, &m->ws_nunion, &m->ws_Glo, &m->ws_Ghi, &m->ws_Ghi2, &m->ws_Gbase, &m->ws_Gdiag, &m->ws_Gmeta, &m->ws_hioff,
-        &m->ws_hi2off, &m->ws_hik, &m->ws_hi2k, &m->ws_rankof, &m->ws_itemof})
+        &m->ws_hi2off, &m->ws_hik, &m->ws_hi2k, &m->ws_rankof, &m->ws_itemof, &m->ws_tkeys[0], &m->ws_tkeys[1],
+        &m->ws_tpay[0], &m->ws_tpay[1], &m->ws_ttmp})
     if (b->p) (void)hipFree(b->p);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -969,7 +1089,8 @@ void drop_float_gram(slimgpu_matrix* m) {
 }  // namespace
 
 slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
-                     int32_t* status, const int32_t* columns, int32_t ncolumns, bool row_view) {
+                     int32_t* status, const int32_t* columns, int32_t ncolumns, bool row_view,
+                     ResidentIO* rio) {
   const double t_begin = now_ms();
   slimgpu_stats_t st;
   std::memset(&st, 0, sizeof(st));
@@ -1217,13 +1338,40 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     // one word per user of their range in LDS (cd_tile.hpp, gbits) -- when that range fits
     int req_cluster = opt.cluster;
     size_t gram_bits_lds = 0;
+    int gram_passes = 1, gram_pass = 0;  // (user passes of the G builder, below)
     if (opt.build_G && use_tile && tileP == 32 && m->binary && !std::getenv("SLIM_GPU_NO_GBITS")) {
       ensure_cluster_split(m, 5);
       const size_t need = sizeof(uint32_t) * (size_t)(round_up(m->max_range_rows[5], 64) + 64);
-      if (need <= 148 * 1024 && m->num_cus >= 32) {
+      // (test hook: pretend a member holds only that many users, so that small matrices take the passes)
+      size_t words_cap = 148 * 1024;
+      if (test_hook("SLIM_GPU_TEST_GBITS_ROWS"))
+        words_cap = sizeof(uint32_t) * (size_t)(round_up(std::max(64, std::atoi(std::getenv("SLIM_GPU_TEST_GBITS_ROWS"))), 64) + 64);
+      if (need <= words_cap && m->num_cus >= 32) {
         gram_bits_lds = need;
         req_cluster = 32;
         tileNW = 16;
+      } else if (m->num_cus >= 32 && !std::getenv("SLIM_GPU_NO_GPASSES")) {
+        // More users than 32 members hold as words (C5: 10M users, 312K per member): the same
+        // kernel in USER PASSES -- np launches over the whole work list, launch s with member k on
+        // range 32 s + k of 32 np ranges of equal nnz, its sums added to G (exact: integer counts).
+        // The id stream is the same 4 bytes per nnz and tile either way (a member reads its
+        // ranges' slices of every column); what passes add is a bitmap build per tile and pass.
+        const int64_t rows_cap = (int64_t)(words_cap / sizeof(uint32_t)) - 128;
+        int np = (int)((m->max_range_rows[5] + rows_cap - 1) / rows_cap);
+        for (; np <= 64; ++np) {
+          ensure_gram_split(m, np);
+          const size_t need_p = sizeof(uint32_t) * (size_t)(round_up(m->gsplit_max_rows, 64) + 64);
+          if (need_p <= words_cap) {
+            gram_bits_lds = need_p;
+            req_cluster = 32;
+            tileNW = 16;
+            gram_passes = np;
+            if (const char* te = std::getenv("SLIM_GPU_TRACE"); te && std::atoi(te) >= 1)
+              std::fprintf(stderr, "[trace] G builder: %d user passes (32 members x %d users at most, %zu KB of words)\n",
+                           np, m->gsplit_max_rows, need_p >> 10);
+            break;
+          }
+        }
       }
     }
     // (four 4-wavefront workgroups per CU were measured too: no gain, even on columns of ~900 nnz)
@@ -1231,7 +1379,13 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     // warm start (estimate.c:453-464) on the tile path: how the previous coefficients are folded
     // into the residual -- "row" (default for 32-wide tiles: one pass over the member's rows,
     // x lines from one copy per cluster) or "col" (one pass per column of the union list)
-    const bool has_imodel = imodel && imodel->colptr && imodel->ncols > 0;
+    const slimgpu_model* warm_dev = rio ? rio->warm : nullptr;  // previous model already in HBM
+    const bool resident = rio && rio->out;                      // the learned model stays in HBM
+    if (warm_dev && warm_dev->device != m->device) {
+      set_error("SLIMGPU_LearnResident: the warm-start model lives on another device");
+      return fail(SLIM_ERROR_INPUT);
+    }
+    const bool has_imodel = warm_dev ? warm_dev->n > 0 : (imodel && imodel->colptr && imodel->ncols > 0);
     bool row_fold = true;
     if (const char* e = std::getenv("SLIM_GPU_FOLD")) row_fold = std::strcmp(e, "col") != 0;
     if (use_tile) {
@@ -1340,6 +1494,8 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       ensure_cluster_split(m, cluster_lg);
       // (+ 64 rows: the spare residual line behind a member's user range, cd_tile.hpp)
       tile_r = (size_t)(round_up(m->max_range_rows[cluster_lg], 64) + 64) * tileP;
+      // (the G builder's word-per-user form keeps no residual: C5 would reserve 10 GB of lines)
+      if (opt.build_G && gram_bits_lds && clusterK == 32 && !force_k1) tile_r = (size_t)64 * tileP;
       tile_x = (size_t)ncols_pad * tileP;
       tile_u = (size_t)ncols_pad;
       nclusters = std::max(1, std::min(ngroups_all, wg_slots / clusterK));
@@ -1447,7 +1603,14 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     const int32_t* d_icolind = nullptr;
     const float* d_icolval = nullptr;
     int32_t incols = 0;
-    if (has_imodel) {
+    const double t_prep_done = now_ms();  // (host phases, SLIM_GPU_TRACE: prep | launches + D2H | counters | columns | row view)
+    double d2h_ms = 0.0;
+    if (has_imodel && warm_dev) {  // no upload: the solver reads the resident column view
+      incols = warm_dev->n;
+      d_icolptr = warm_dev->d_colptr;
+      d_icolind = warm_dev->d_colind;
+      d_icolval = warm_dev->d_colval;
+    } else if (has_imodel) {
       incols = imodel->ncols;
       const int64_t innz = imodel->colptr[incols];
       int64_t* p = ws_get<int64_t>(m->ws_icolptr, (size_t)incols + 1);
@@ -1500,6 +1663,11 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     std::vector<int64_t> h_off((size_t)ncols, 0);
     std::vector<int32_t> h_ind;
     std::vector<float> h_val;
+    // resident models: the arenas of the launches stay in HBM (one, unless a column overflowed)
+    struct ArenaSeg { int32_t* ind; float* val; int64_t n; bool owned; };
+    struct ArenaSegs : std::vector<ArenaSeg> {
+      ~ArenaSegs() { for (auto& g : *this) if (g.owned) { (void)hipFree(g.ind); (void)hipFree(g.val); } }
+    } arena_segs;
     std::vector<int32_t> pending = order;  // columns still to solve
     double kernel_ms = 0;
     // results per column (host), filled as launches complete
@@ -1608,6 +1776,19 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       // per wavefront and 32 ballots per 64 nnz)
       S.gram_bits = (gram_bits_lds && clusterK == 32 && tile_lds == gram_bits_lds) ? 2 : 0;
       if (const char* e = std::getenv("SLIM_GPU_GBITS"); e && S.gram_bits) S.gram_bits = std::atoi(e) == 1 ? 1 : 2;
+      S.gram_split_stride = clusterK + 1;
+      S.gram_accum = 0;
+      if (gram_passes > 1) {
+        if (S.gram_bits) {  // pass gram_pass of gram_passes: this launch's 32 user ranges
+          S.ubounds = m->d_gubounds + 32 * gram_pass;
+          S.csplit = m->d_gcsplit + 32 * gram_pass;
+          S.gram_split_stride = 32 * gram_passes + 1;
+          S.gram_accum = gram_pass > 0;
+        } else {  // (re-planned without clusters: one launch forms all of G from the top)
+          gram_passes = 1;
+          gram_pass = 0;
+        }
+      }
       if (opt.build_G) {
         if (attempt > 0 || cluster_fallback || npend != ncols) {
           // (the symmetric fill needs every column in ONE launch; a re-plan after a cluster
@@ -1799,6 +1980,10 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
                   "(were all workgroups resident?)");
         return fail(SLIM_ERROR);
       }
+      if (gram_passes > 1 && ++gram_pass < gram_passes) {
+        --attempt;  // the same work list again, over the next user ranges
+        continue;
+      }
       if (S.gram_mode == 1) {  // the launch completed: its screen sums are reusable
         m->gram_order = order;
         std::copy(gram_geom_now, gram_geom_now + 6, m->gram_geom);
@@ -1807,15 +1992,21 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       std::memcpy(&cursor, h_misc + 2, sizeof(cursor));
       const int64_t used = std::min<int64_t>((int64_t)cursor, arena_cap);
       const int64_t base = fin_total;
-      h_ind.resize((size_t)(base + used));
-      h_val.resize((size_t)(base + used));
-      if (used > 0) {
-        HIP_TRY(hipMemcpyAsync(h_ind.data() + base, d_ai, sizeof(int32_t) * (size_t)used,
-                               hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(h_val.data() + base, d_av, sizeof(float) * (size_t)used,
-                               hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+      const double t_d2h = now_ms();
+      if (resident) {  // the arena stays where it is; a retry (below) moves it aside first
+        arena_segs.push_back({d_ai, d_av, used, false});
+      } else {
+        h_ind.resize((size_t)(base + used));
+        h_val.resize((size_t)(base + used));
+        if (used > 0) {
+          HIP_TRY(hipMemcpyAsync(h_ind.data() + base, d_ai, sizeof(int32_t) * (size_t)used,
+                                 hipMemcpyDeviceToHost, stream));
+          HIP_TRY(hipMemcpyAsync(h_val.data() + base, d_av, sizeof(float) * (size_t)used,
+                                 hipMemcpyDeviceToHost, stream));
+          HIP_TRY(hipStreamSynchronize(stream));
+        }
       }
+      d2h_ms += now_ms() - t_d2h;
       fin_total += used;
 
       std::vector<int32_t> again;
@@ -1831,6 +2022,15 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       }
       pending.swap(again);
       if (!pending.empty()) arena_cap = std::max<int64_t>(arena_cap, need + 1024);
+      if (resident && !pending.empty() && used > 0) {  // the next attempt overwrites the arena
+        ArenaSeg& sg = arena_segs.back();
+        int32_t* ki = dev_alloc<int32_t>((size_t)used);
+        float* kv = dev_alloc<float>((size_t)used);
+        HIP_TRY(hipMemcpyAsync(ki, sg.ind, sizeof(int32_t) * (size_t)used, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(kv, sg.val, sizeof(float) * (size_t)used, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        sg = {ki, kv, used, true};
+      }
     }
     if (!pending.empty()) {
       set_error("SLIMGPU_Learn: output arena overflow persisted");
@@ -1871,11 +2071,65 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     HIP_TRY(hipMemcpy(h_obj.data(), d_stf + ncols, sizeof(float) * (size_t)ncols, hipMemcpyDeviceToHost));
 
     // SaveModel (estimate.c:570-593): concatenate the columns, then the row view
+    const double t_counters_done = now_ms();
     int64_t tnnz = 0;
     for (int32_t c = 0; c < ncols; ++c) tnnz += fin_cnt[c];
-    auto* colptr = static_cast<ssize_t*>(std::malloc(sizeof(ssize_t) * ((size_t)ncols + 1)));
-    auto* colind = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(tnnz, 1)));
-    auto* colval = static_cast<float*>(std::malloc(sizeof(float) * (size_t)std::max<int64_t>(tnnz, 1)));
+    slim_csr_t* model = nullptr;
+    double t_columns_done = t_counters_done;
+    ssize_t* colptr = nullptr;
+    int32_t* colind = nullptr;
+    float* colval = nullptr;
+    if (resident) {
+      // the same two steps on the device: the arena's columns gathered into column order, the row
+      // view by the staging pass's stable sort (engine.hip: transpose_on_device) -- nothing crosses
+      // PCIe unless the caller fetches the model (model_fetch)
+      std::unique_ptr<slimgpu_model> dm(new slimgpu_model());
+      dm->device = m->device;
+      dm->n = ncols;
+      dm->nnz = tnnz;
+      std::vector<int64_t> h_colptr((size_t)ncols + 1, 0);
+      for (int32_t c = 0; c < ncols; ++c) h_colptr[(size_t)c + 1] = h_colptr[(size_t)c] + fin_cnt[(size_t)c];
+      const int32_t* src_i = arena_segs.empty() ? nullptr : arena_segs[0].ind;
+      const float* src_v = arena_segs.empty() ? nullptr : arena_segs[0].val;
+      int32_t* cat_i = nullptr;
+      float* cat_v = nullptr;
+      if (arena_segs.size() > 1) {  // (a column overflowed its arena: the launches' pieces, in order)
+        cat_i = dev_alloc<int32_t>((size_t)std::max<int64_t>(fin_total, 1));
+        cat_v = dev_alloc<float>((size_t)std::max<int64_t>(fin_total, 1));
+        int64_t at = 0;
+        for (const ArenaSeg& sg : arena_segs) {
+          if (sg.n > 0) {
+            HIP_TRY(hipMemcpyAsync(cat_i + at, sg.ind, sizeof(int32_t) * (size_t)sg.n, hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(cat_v + at, sg.val, sizeof(float) * (size_t)sg.n, hipMemcpyDeviceToDevice, stream));
+          }
+          at += sg.n;
+        }
+        src_i = cat_i;
+        src_v = cat_v;
+      }
+      dm->d_colptr = dev_alloc<int64_t>((size_t)ncols + 1);
+      dm->d_colind = dev_alloc<int32_t>((size_t)std::max<int64_t>(tnnz, 1));
+      dm->d_colval = dev_alloc<float>((size_t)std::max<int64_t>(tnnz, 1));
+      int64_t* d_src = ws_get<int64_t>(m->ws_off, (size_t)ncols, m);  // (the solver's own offsets: done with)
+      HIP_TRY(hipMemcpyAsync(dm->d_colptr, h_colptr.data(), sizeof(int64_t) * ((size_t)ncols + 1),
+                             hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipMemcpyAsync(d_src, fin_off.data(), sizeof(int64_t) * (size_t)ncols, hipMemcpyHostToDevice, stream));
+      if (tnnz > 0) {
+        hipLaunchKernelGGL(k_gather_columns, dim3(grid_for((int64_t)ncols * 64, 256, m->num_cus * 16)), dim3(256),
+                           0, stream, ncols, dm->d_colptr, d_src, src_i, src_v, dm->d_colind, dm->d_colval);
+        HIP_TRY(hipGetLastError());
+      }
+      t_columns_done = now_ms();
+      if (row_view) transpose_on_device(m, ncols, tnnz, dm->d_colptr, dm->d_colind, dm->d_colval, &dm->d_rowptr,
+                                        &dm->d_rowind, &dm->d_rowval);
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (cat_i) (void)hipFree(cat_i);
+      if (cat_v) (void)hipFree(cat_v);
+      *rio->out = dm.release();
+    } else {
+    colptr = static_cast<ssize_t*>(std::malloc(sizeof(ssize_t) * ((size_t)ncols + 1)));
+    colind = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (size_t)std::max<int64_t>(tnnz, 1)));
+    colval = static_cast<float*>(std::malloc(sizeof(float) * (size_t)std::max<int64_t>(tnnz, 1)));
     if (!colptr || !colind || !colval) {
       std::free(colptr); std::free(colind); std::free(colval);
       set_error("SLIMGPU_Learn: out of host memory for the model");
@@ -1890,9 +2144,16 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       }
       colptr[c + 1] = colptr[c] + n;
     }
-    slim_csr_t* model = model_from_columns(ncols, colptr, colind, colval, row_view);
+    t_columns_done = now_ms();
+    model = model_from_columns(ncols, colptr, colind, colval, row_view);
+    }
+    if (trace_level >= 1)
+      std::fprintf(stderr, "[slim_gpu trace] host phases: prep %.0f ms, launches + D2H %.0f ms (kernel %.0f, D2H of "
+                   "%lld entries %.0f), counters %.0f ms, columns %.0f ms, row view %.0f ms\n",
+                   t_prep_done - t_begin, t_kernel_done - t_prep_done, kernel_ms, (long long)fin_total, d2h_ms,
+                   t_counters_done - t_kernel_done, t_columns_done - t_counters_done, now_ms() - t_columns_done);
 
-    if (opt.dbglvl & SLIM_DBG_PROGRESS) {
+    if ((opt.dbglvl & SLIM_DBG_PROGRESS) && model) {
       // estimate.c:507-514: one line per solved column, in column order (the reference prints
       // them as its threads finish).  Everything but "a0s" comes from the counters the kernels
       // return; a0s (ComputeAvgZeroScore, estimate.c:627-662: the mean of the 10 largest
@@ -1991,6 +2252,155 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     set_error("SLIMGPU_Learn: out of host memory");
     return fail(SLIM_ERROR_MEMORY);
   }
+}
+
+// -- models resident in HBM (engine.hpp) -----------------------------------------------------
+slimgpu_model* learn_resident(slimgpu_matrix_t* m, const LearnOptions& opt, const slimgpu_model* warm,
+                              int32_t* status) {
+  if (m && !m->replicas.empty()) {
+    set_error("SLIMGPU_LearnResident: a model resident in HBM belongs to one device (ngpus = 1)");
+    if (status) *status = SLIM_ERROR_INPUT;
+    return nullptr;
+  }
+  slimgpu_model* out = nullptr;
+  ResidentIO rio;
+  rio.warm = warm;
+  rio.out = &out;
+  int32_t st = SLIM_ERROR;
+  (void)learn_cd(m, opt, nullptr, &st, nullptr, 0, /*row_view=*/true, &rio);
+  if (status) *status = st;
+  if (st != SLIM_OK && out) {
+    model_free(out);
+    out = nullptr;
+  }
+  return out;
+}
+
+int32_t model_row_view(const slimgpu_model* w, DeviceRowView* out) {
+  if (!w || !w->d_rowptr || !out) {
+    set_error("resident model: no row view");
+    return SLIM_ERROR_INPUT;
+  }
+  try {
+    HIP_TRY(hipSetDevice(w->device));
+    std::vector<int64_t> rp((size_t)w->n + 1);
+    HIP_TRY(hipMemcpy(rp.data(), w->d_rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost));
+    out->nrows = out->ncols = w->n;
+    out->nnz = w->nnz;
+    out->max_row = 0;
+    for (int32_t r = 0; r < w->n; ++r) out->max_row = std::max<int64_t>(out->max_row, rp[(size_t)r + 1] - rp[(size_t)r]);
+    out->d_ptr = w->d_rowptr;
+    out->d_ind = w->d_rowind;
+    out->d_val = w->d_rowval;
+    return SLIM_OK;
+  } catch (const HipError& e) {
+    report(e, "resident model");
+    return status_of(e);
+  }
+}
+
+int64_t model_nnz(const slimgpu_model* w) { return w ? w->nnz : -1; }
+int32_t model_ncols(const slimgpu_model* w) { return w ? w->n : -1; }
+
+namespace {
+// D2H of both views into arrays the host model owns (csr_free releases them)
+void fetch_now(slimgpu_model* w) {
+  const double t0 = now_ms();
+  ssize_t *cp = nullptr, *rp = nullptr;
+  int32_t *ci = nullptr, *ri = nullptr;
+  float *cv = nullptr, *rv = nullptr;
+  hipStream_t cs = nullptr;
+  try {
+    HIP_TRY(hipSetDevice(w->device));
+    static_assert(sizeof(ssize_t) == sizeof(int64_t), "offsets travel as they are");
+    const size_t n1 = (size_t)w->n + 1, nz = (size_t)std::max<int64_t>(w->nnz, 1);
+    cp = static_cast<ssize_t*>(std::malloc(sizeof(ssize_t) * n1));
+    rp = static_cast<ssize_t*>(std::malloc(sizeof(ssize_t) * n1));
+    ci = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * nz));
+    ri = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * nz));
+    cv = static_cast<float*>(std::malloc(sizeof(float) * nz));
+    rv = static_cast<float*>(std::malloc(sizeof(float) * nz));
+    if (!cp || !rp || !ci || !ri || !cv || !rv) throw std::bad_alloc();
+    // its own stream: the copies run on the DMA engines beside whatever the solver's stream is doing
+    HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    HIP_TRY(hipMemcpyAsync(cp, w->d_colptr, sizeof(int64_t) * n1, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipMemcpyAsync(rp, w->d_rowptr, sizeof(int64_t) * n1, hipMemcpyDeviceToHost, cs));
+    if (w->nnz > 0) {
+      HIP_TRY(hipMemcpyAsync(ci, w->d_colind, sizeof(int32_t) * (size_t)w->nnz, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipMemcpyAsync(cv, w->d_colval, sizeof(float) * (size_t)w->nnz, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipMemcpyAsync(ri, w->d_rowind, sizeof(int32_t) * (size_t)w->nnz, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipMemcpyAsync(rv, w->d_rowval, sizeof(float) * (size_t)w->nnz, hipMemcpyDeviceToHost, cs));
+    }
+    HIP_TRY(hipStreamSynchronize(cs));
+    (void)hipStreamDestroy(cs);
+    cs = nullptr;
+    slim_csr_t* hm = model_from_columns(w->n, cp, ci, cv, /*row_view=*/false);
+    if (!hm) throw std::bad_alloc();
+    hm->rowptr = rp;
+    hm->rowind = ri;
+    hm->rowval = rv;
+    w->fetched = hm;
+    w->fetch_status = SLIM_OK;
+  } catch (const HipError& e) {
+    w->fetch_error = "SLIMGPU_ModelFetch: " + e.where + ": " + hipGetErrorString(e.code);
+    w->fetch_status = SLIM_ERROR;
+  } catch (const std::bad_alloc&) {
+    w->fetch_error = "SLIMGPU_ModelFetch: out of host memory";
+    w->fetch_status = SLIM_ERROR_MEMORY;
+  }
+  if (w->fetch_status != SLIM_OK) {
+    if (cs) (void)hipStreamDestroy(cs);
+    std::free(cp); std::free(rp); std::free(ci); std::free(ri); std::free(cv); std::free(rv);
+  }
+  w->fetch_ms = now_ms() - t0;
+}
+}  // namespace
+
+int32_t model_fetch_begin(slimgpu_model* w) {
+  if (!w || !w->d_rowptr) {
+    set_error("SLIMGPU_ModelFetchBegin: null model");
+    return SLIM_ERROR_INPUT;
+  }
+  if (w->fetch_begun) return SLIM_OK;
+  w->fetch_begun = true;
+  w->fetched = nullptr;
+  w->fetch_status = SLIM_OK;
+  try {
+    w->fetcher = std::thread(fetch_now, w);
+  } catch (const std::system_error&) {  // no thread: the fetch happens in model_fetch
+    w->fetch_begun = false;
+  }
+  return SLIM_OK;
+}
+
+slim_csr_t* model_fetch(slimgpu_model* w, int32_t* status, double* ms) {
+  if (!w || !w->d_rowptr) {
+    set_error("SLIMGPU_ModelFetch: null model");
+    if (status) *status = SLIM_ERROR_INPUT;
+    return nullptr;
+  }
+  if (w->fetch_begun) {
+    if (w->fetcher.joinable()) w->fetcher.join();
+    w->fetch_begun = false;
+  } else {
+    fetch_now(w);
+  }
+  slim_csr_t* hm = w->fetched;  // the caller's from here on (SLIM_FreeModel); a later fetch copies again
+  w->fetched = nullptr;
+  if (w->fetch_status != SLIM_OK) set_error(w->fetch_error);
+  if (status) *status = w->fetch_status;
+  if (ms) *ms = w->fetch_ms;
+  return hm;
+}
+
+void model_free(slimgpu_model* w) {
+  if (!w) return;
+  if (w->fetcher.joinable()) w->fetcher.join();
+  if (w->fetched) csr_free(w->fetched);
+  (void)hipSetDevice(w->device);
+  (void)hipFree(w->d_colptr); (void)hipFree(w->d_colind); (void)hipFree(w->d_colval);
+  (void)hipFree(w->d_rowptr); (void)hipFree(w->d_rowind); (void)hipFree(w->d_rowval);
+  delete w;
 }
 
 // -- G = R^T R in row blocks (engine.hpp) ---------------------------------------------------

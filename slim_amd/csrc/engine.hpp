@@ -69,9 +69,27 @@ int32_t gram_commit(slimgpu_matrix_t* m);
 // (slim_csr_t with both views) or nullptr with *status set.
 // columns/ncolumns (optional): solve exactly these item columns (distinct ids) instead of
 // the range [opt.col_begin, opt.col_end); every other column of the model comes back empty.
+// rio (optional): warm start from / result into a model resident in HBM (below); with rio->out set
+// the host model is not formed and nullptr comes back with *status = SLIM_OK.
+struct ResidentIO {
+  const slimgpu_model* warm = nullptr;
+  slimgpu_model** out = nullptr;
+};
 slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_csr_t* imodel,
                      int32_t* status, const int32_t* columns = nullptr, int32_t ncolumns = 0,
-                     bool row_view = true);
+                     bool row_view = true, ResidentIO* rio = nullptr);
+
+// Models resident in HBM (model-selection grids: slim_mselect.c:94-113 learns 45 models one from the
+// other and needs each on the host only to print its nnz): the solve leaves both views of W on the
+// device, the next solve warm-starts from them without an upload, and a fetch to the host (both views,
+// the arrays SaveModel would have formed) can run on the DMA engines beside the next solve.
+slimgpu_model* learn_resident(slimgpu_matrix_t* m, const LearnOptions& opt, const slimgpu_model* warm,
+                              int32_t* status);
+int64_t model_nnz(const slimgpu_model* w);
+int32_t model_ncols(const slimgpu_model* w);
+int32_t model_fetch_begin(slimgpu_model* w);                      // starts the D2H on a host thread + copy stream
+slim_csr_t* model_fetch(slimgpu_model* w, int32_t* status, double* ms = nullptr);  // joins it (or copies now)
+void model_free(slimgpu_model* w);
 
 // Replicas: copies of a staged matrix on other devices, owned by (and freed with) the
 // primary handle; matrix_adopt_csr hands the borrowed device CSR of a FromDevice matrix over
@@ -97,6 +115,17 @@ int32_t device_count();
 // to host_csr.cpp::top_n.  counts (optional): list length per user.
 int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcmds,
                        int32_t* output, float* scores, int32_t* counts);
+// the same with the row view of W already on the device (a resident model: model_row_view)
+struct DeviceRowView {
+  int32_t nrows = 0, ncols = 0;
+  int64_t nnz = 0, max_row = 0;  // max_row: entries of the longest row
+  const int64_t* d_ptr = nullptr;
+  const int32_t* d_ind = nullptr;
+  const float* d_val = nullptr;
+};
+int32_t predict_device_view(const DeviceRowView& W, const slim_csr_t* hist, int32_t nrcmds,
+                            int32_t* output, float* scores, int32_t* counts);
+int32_t model_row_view(const slimgpu_model* w, DeviceRowView* out);
 
 // admm.hip: SLIM_Learn(algo = admm), the reference's dense ADMM solver (estimate.c:38-304) with
 // rocBLAS for the panel solves, updates and products and HIP kernels for the rest.

@@ -63,21 +63,43 @@ int main(int argc, char** argv) {
     SLIMGPU_MatrixExpectSolves(R, npairs);
   }
   slim_t* model = nullptr;
+  slimgpu_model_t* dmodel = nullptr;
+  const char* ng_env = std::getenv("SLIM_GPU_NGPUS");
+  const char* res_env = std::getenv("SLIM_GPU_RESIDENT");
+  const bool resident = !(a.has("ngpus") && a.integer("ngpus", 1) > 1) && !(ng_env && std::atoi(ng_env) > 1) &&
+                        !(res_env && std::atoi(res_env) == 0);
   double best_hr = 0, best_ar = 0, bh_l1 = 0, bh_l2 = 0, ba_l1 = 0, ba_l2 = 0;
   while (std::fgets(line, sizeof line, lf)) {
     double l1, l2;
     if (std::sscanf(line, "%lf %lf", &l1, &l2) != 2) continue;  // slim_mselect.c:100-101
     dopt[SLIM_OPTION_L1R] = l1;
     dopt[SLIM_OPTION_L2R] = l2;
-    slim_t* next = SLIMGPU_Learn(R, io, dopt, model, &status);  // warm start, :103-113
-    SLIM_FreeModel(&model);
-    model = next;
-    if (!model) {
+    // the model stays in HBM (SLIMGPU_LearnResident): warm start without an upload, scored where it
+    // lies; with model files wanted it is fetched beside nothing -- the write needs it at once
+    // (a model sharded over several GPUs is assembled on the host: SLIMGPU_Learn as before)
+    if (!resident) {
+      slim_t* next = SLIMGPU_Learn(R, io, dopt, model, &status);  // warm start, :103-113
+      SLIM_FreeModel(&model);
+      model = next;
+    } else {
+      slimgpu_model_t* dnext = SLIMGPU_LearnResident(R, io, dopt, dmodel, &status);  // warm start, :103-113
+      SLIMGPU_ModelFree(&dmodel);
+      dmodel = dnext;
+      SLIM_FreeModel(&model);
+    }
+    if (resident ? !dmodel : !model) {
       std::printf("ERROR: model estimation failed [%.3le %.3le]: rstatus %d\n", l1, l2, status);
       continue;
     }
     slimgpu_stats_t st;
     SLIMGPU_LastStats(&st);
+    if (resident && !a.has("nomodels")) {
+      model = SLIMGPU_ModelFetch(dmodel, &status);
+      if (!model) {
+        std::printf("ERROR: model fetch failed [%.3le %.3le]: rstatus %d\n", l1, l2, status);
+        continue;
+      }
+    }
     if (!a.has("nomodels")) {
       std::string name(line);
       while (!name.empty() && (name.back() == '\n' || name.back() == '\r')) name.pop_back();
@@ -85,13 +107,17 @@ int main(int argc, char** argv) {
     }
     std::vector<int32_t> lists((size_t)trn.nrows * nrcmds, -1), lens(trn.nrows, 0);
     std::vector<float> scores((size_t)trn.nrows * nrcmds, 0.0f);
-    if (Py_SLIM_Predict(nrcmds, model, hold, lists.data(), scores.data()) != SLIM_OK) continue;
+    if (!resident) {
+      if (Py_SLIM_Predict(nrcmds, model, hold, lists.data(), scores.data()) != SLIM_OK) continue;
+    } else if (SLIMGPU_ModelPredict(nrcmds, dmodel, hold, lists.data(), scores.data()) != SLIM_OK) {
+      if (!model) model = SLIMGPU_ModelFetch(dmodel, &status);  // (lists beyond the GPU scorer's 128: host loop)
+      if (!model || Py_SLIM_Predict(nrcmds, model, hold, lists.data(), scores.data()) != SLIM_OK) continue;
+    }
     for (int32_t u = 0; u < trn.nrows; ++u)
       while (lens[u] < nrcmds && lists[(size_t)u * nrcmds + lens[u]] >= 0) ++lens[u];
     const Eval e = evaluate_lists(tst, lists, lens, nrcmds, fmarker, ncols);
-    const slim_csr_t* W = static_cast<slim_csr_t*>(model);
     std::printf("l1r: %.2le l2r: %.2le nnz: %7zd hr: %.4f hr_head: %.4f hr_tail: %.4f arhr: %.4f time: %.2lf\n",
-                l1, l2, W->rowptr[W->nrows], e.hr, e.hr_head, e.hr_tail, e.arhr, st.total_ms / 1e3);
+                l1, l2, resident ? (ssize_t)SLIMGPU_ModelNnz(dmodel) : static_cast<slim_csr_t*>(model)->rowptr[static_cast<slim_csr_t*>(model)->nrows], e.hr, e.hr_head, e.hr_tail, e.arhr, st.total_ms / 1e3);
     if (e.hr > best_hr) { best_hr = e.hr; bh_l1 = l1; bh_l2 = l2; }
     if (e.arhr > best_ar) { best_ar = e.arhr; ba_l1 = l1; ba_l2 = l2; }
   }
@@ -100,6 +126,7 @@ int main(int argc, char** argv) {
               bh_l2, best_ar, ba_l1, ba_l2);
   std::printf("\nDone.\n------------------------------------------------------------------\n");
   SLIM_FreeModel(&model);
+  SLIMGPU_ModelFree(&dmodel);
   std::free(fmarker);
   Py_csr_free(hold);
   SLIMGPU_MatrixFree(&R);

@@ -219,6 +219,13 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
 
   *bestHRHR = *bestARHR = *bestHRAR = *bestARAR = 0.0;
   slim_csr_t* model = nullptr;
+  // One GPU, CD: the models of the grid stay in HBM (engine.hpp: learn_resident) -- each pair is
+  // warm-started from the previous one without an upload and scored where it lies; only its nnz is
+  // printed, so nothing of it ever crosses PCIe.  SLIM_GPU_RESIDENT=0: host models as before.
+  const char* res_env = std::getenv("SLIM_GPU_RESIDENT");
+  const bool resident = !admm && mat && matrix_replicas(mat).empty() && nrcmds >= 1 && nrcmds <= 128 &&
+                        !(res_env && std::atoi(res_env) == 0);
+  slimgpu_model* dmodel = nullptr;
   int32_t rc = SLIM_OK;
   for (int32_t a = 0; a < nl1 && rc == SLIM_OK; ++a) {
     for (int32_t b = 0; b < nl2; ++b) {
@@ -228,6 +235,31 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
       opt.l1r = arrayl1[a];
       opt.l2r = arrayl2[b];
       slim_csr_t* prev = model;  // warm start from the previous cell
+      // top-N of every user on the GPU (bit-identical to the host scorer), hits on the host
+      std::vector<int32_t> lists((size_t)trn->nrows * nrcmds, -1), lens((size_t)trn->nrows, 0);
+      std::vector<float> lsc((size_t)trn->nrows * nrcmds, 0.0f);
+      bool on_gpu = false;
+      ssize_t model_nnz_now = 0;
+      if (resident) {
+        slimgpu_model* dprev = dmodel;
+        dmodel = learn_resident(mat, opt, dprev, &status);
+        model_free(dprev);
+        if (!dmodel) {
+          rc = status;
+          break;
+        }
+        model_nnz_now = (ssize_t)model_nnz(dmodel);
+        DeviceRowView wv;
+        on_gpu = model_row_view(dmodel, &wv) == SLIM_OK &&
+                 predict_device_view(wv, trn, nrcmds, lists.data(), lsc.data(), lens.data()) == SLIM_OK;
+        if (!on_gpu) {  // (the scorer refused: the host loop needs the host model)
+          model = model_fetch(dmodel, &status);
+          if (!model) {
+            rc = status;
+            break;
+          }
+        }
+      } else {
       // (ADMM ignores the previous model, estimate.c:38)
       model = admm ? learn_admm(trn->nrows, trn->rowptr, trn->rowind, trn->rowval, opt, &status)
                    : multi_learn(mat, opt, prev, &status);
@@ -236,21 +268,30 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
         rc = status;
         break;
       }
-      // top-N of every user on the GPU (bit-identical to the host scorer), hits on the host
-      std::vector<int32_t> lists((size_t)trn->nrows * nrcmds, -1), lens((size_t)trn->nrows, 0);
-      std::vector<float> lsc((size_t)trn->nrows * nrcmds, 0.0f);
-      const bool on_gpu = nrcmds <= 128 && predict_device(model, trn, nrcmds, lists.data(),
-                                                          lsc.data(), lens.data()) == SLIM_OK;
+      model_nnz_now = model->rowptr[model->nrows];
+      on_gpu = nrcmds <= 128 && predict_device(model, trn, nrcmds, lists.data(),
+                                               lsc.data(), lens.data()) == SLIM_OK;
+      }
       EvalResult ev;
       if (!on_gpu)
         ev = evaluate(model, trn, tst, nrcmds, fmarker, ncols);
       else if (evaluate_device(std::min(trn->nrows, tst->nrows), nrcmds, lists.data(), lens.data(),
-                               tst, fmarker, ncols, &ev) != SLIM_OK)  // hit counting on the GPU
+                               tst, fmarker, ncols, &ev) != SLIM_OK) {  // hit counting on the GPU
+        if (resident && !model) model = model_fetch(dmodel, &status);  // (the host loop sizes by the model)
+        if (!model) {
+          rc = status;
+          break;
+        }
         ev = evaluate(model, trn, tst, nrcmds, fmarker, ncols, lists.data(), lens.data());
+      }
       std::printf("l1r: %.2le l2r: %.2le nnz: %7zd hr: %.4f hr_head: %.4f hr_tail: %.4f "
                   "arhr: %.4f time: %.2lf\n",
-                  opt.l1r, opt.l2r, model->rowptr[model->nrows], ev.hr, ev.hr_head, ev.hr_tail,
+                  opt.l1r, opt.l2r, model_nnz_now, ev.hr, ev.hr_head, ev.hr_tail,
                   ev.arhr, last_stats().total_ms / 1e3);
+      if (resident && model) {  // (a fetched copy served the host scorer only)
+        csr_free(model);
+        model = nullptr;
+      }
       if (ev.nvalid < 1) {  // pyapi.c:377-381
         *bestl1HR = opt.l1r;
         *bestl2HR = opt.l2r;
@@ -273,6 +314,7 @@ int32_t Py_SLIM_Mselect(slim_t* trnhandle, slim_t* tsthandle, int32_t* ioptions,
   }
   std::printf("\nDone.\n------------------------------------------------------------------\n");
   csr_free(model);
+  model_free(dmodel);
   std::free(fmarker);
   matrix_free(mat);
   return rc;
@@ -439,6 +481,49 @@ slim_t* SLIMGPU_Learn(slimgpu_matrix_t* mat, int32_t* ioptions, double* doptions
   }
   if (r_status) *r_status = status;
   return model;
+}
+
+slimgpu_model_t* SLIMGPU_LearnResident(slimgpu_matrix_t* mat, int32_t* ioptions, double* doptions,
+                                       const slimgpu_model_t* warm, int32_t* r_status) {
+  set_error("");
+  int32_t status = SLIM_ERROR;
+  LearnOptions opt = decode_options(ioptions, doptions);
+  slimgpu_model_t* model = nullptr;
+  if (opt.algo != SLIM_ALGO_CD) {
+    set_error("SLIMGPU_LearnResident: only algo=cd is implemented");
+    status = SLIM_ERROR_INPUT;
+  } else {
+    model = learn_resident(mat, opt, warm, &status);
+  }
+  if (r_status) *r_status = status;
+  return model;
+}
+
+int64_t SLIMGPU_ModelNnz(const slimgpu_model_t* model) { return model_nnz(model); }
+
+int32_t SLIMGPU_ModelFetchBegin(slimgpu_model_t* model) {
+  set_error("");
+  return model_fetch_begin(model);
+}
+
+slim_t* SLIMGPU_ModelFetch(slimgpu_model_t* model, int32_t* r_status) {
+  set_error("");
+  return model_fetch(model, r_status);
+}
+
+void SLIMGPU_ModelFree(slimgpu_model_t** model) {
+  if (!model || !*model) return;
+  model_free(*model);
+  *model = nullptr;
+}
+
+int32_t SLIMGPU_ModelPredict(int32_t nrcmds, const slimgpu_model_t* model, slim_t* trnhandle,
+                             int32_t* output, float* scores) {
+  set_error("");
+  DeviceRowView v;
+  const int32_t rc = model_row_view(model, &v);
+  if (rc != SLIM_OK) return rc;
+  return predict_device_view(v, as_csr(trnhandle), nrcmds, output, scores, nullptr);
 }
 
 slim_t* SLIMGPU_LearnColumns(slimgpu_matrix_t* mat, int32_t ncolumns, const int32_t* columns,

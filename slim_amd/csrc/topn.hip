@@ -501,15 +501,17 @@ struct DevBuf {
 
 // Top-N lists of every history row.  output/scores are [nusers][nrcmds], slots beyond a
 // user's list length are left as the caller filled them; counts (optional) = list lengths.
-int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcmds,
-                       int32_t* output, float* scores, int32_t* counts) {
-  if (!W || !hist || !W->rowptr || !hist->rowptr || nrcmds < 1 || nrcmds > 128) {
+// W: its row view on the device -- uploaded by predict_device (host model), or where a resident model
+// already holds it (predict_device_view: nothing of W crosses PCIe).
+int32_t predict_device_view(const DeviceRowView& W, const slim_csr_t* hist, int32_t nrcmds,
+                            int32_t* output, float* scores, int32_t* counts) {
+  if (!hist || !hist->rowptr || !W.d_ptr || nrcmds < 1 || nrcmds > 128) {
     set_error("SLIMGPU_Predict: bad arguments (1 <= nrcmds <= 128)");
     return SLIM_ERROR_INPUT;
   }
   const int32_t nusers = hist->nrows;
-  const int32_t ncols = std::max(W->ncols, 1);
-  const int64_t wnnz = W->rowptr[W->nrows], hnnz = hist->rowptr[nusers];
+  const int32_t ncols = std::max(W.ncols, 1);
+  const int64_t wnnz = W.nnz, hnnz = hist->rowptr[nusers];
   const auto t_begin = std::chrono::steady_clock::now();
   try {
     (void)hipGetLastError();  // a failure of an earlier call must not be reported by this one
@@ -520,17 +522,15 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
     int dev = 0;
     TOPN_TRY(hipGetDevice(&dev));
     TOPN_TRY(hipGetDeviceProperties(&prop, dev));
-    DevBuf<int64_t> d_wptr((size_t)W->nrows + 1), d_hptr((size_t)nusers + 1);
-    DevBuf<int32_t> d_wind((size_t)wnnz), d_hind((size_t)hnnz);
-    DevBuf<float> d_wval((size_t)wnnz), d_hval(hist->rowval ? (size_t)hnnz : 1);
+    struct { const int64_t* p; } d_wptr{W.d_ptr};
+    struct { const int32_t* p; } d_wind{W.d_ind};
+    struct { const float* p; } d_wval{W.d_val};
+    DevBuf<int64_t> d_hptr((size_t)nusers + 1);
+    DevBuf<int32_t> d_hind((size_t)hnnz);
+    DevBuf<float> d_hval(hist->rowval ? (size_t)hnnz : 1);
     DevBuf<float> d_oscore((size_t)nusers * nrcmds);
     DevBuf<int32_t> d_oid((size_t)nusers * nrcmds), d_ocnt((size_t)nusers), d_queue(2);
-    TOPN_TRY(hipMemcpy(d_wptr.p, W->rowptr, sizeof(int64_t) * ((size_t)W->nrows + 1), hipMemcpyHostToDevice));
     TOPN_TRY(hipMemcpy(d_hptr.p, hist->rowptr, sizeof(int64_t) * ((size_t)nusers + 1), hipMemcpyHostToDevice));
-    if (wnnz) {
-      TOPN_TRY(hipMemcpy(d_wind.p, W->rowind, sizeof(int32_t) * (size_t)wnnz, hipMemcpyHostToDevice));
-      TOPN_TRY(hipMemcpy(d_wval.p, W->rowval, sizeof(float) * (size_t)wnnz, hipMemcpyHostToDevice));
-    }
     if (hnnz) {
       TOPN_TRY(hipMemcpy(d_hind.p, hist->rowind, sizeof(int32_t) * (size_t)hnnz, hipMemcpyHostToDevice));
       if (hist->rowval)
@@ -548,8 +548,8 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
     if (chunked) {
       int32_t unsorted = 0;
       if (wnnz > 0) {
-        hipLaunchKernelGGL(k_rows_sorted, dim3(std::max(1, std::min(W->nrows / 4 + 1, prop.multiProcessorCount * 8))),
-                           dim3(256), 0, 0, W->nrows, d_wptr.p, d_wind.p, d_queue.p + 1);
+        hipLaunchKernelGGL(k_rows_sorted, dim3(std::max(1, std::min(W.nrows / 4 + 1, prop.multiProcessorCount * 8))),
+                           dim3(256), 0, 0, W.nrows, d_wptr.p, d_wind.p, d_queue.p + 1);
         TOPN_TRY(hipGetLastError());
         TOPN_TRY(hipMemcpy(&unsorted, d_queue.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
       }
@@ -560,7 +560,7 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
     // discovery keys: 32 bits when (longest history, longest model row) fit, else 64
     int64_t max_hist = 0, max_row = 0;
     for (int32_t u = 0; u < nusers; ++u) max_hist = std::max<int64_t>(max_hist, hist->rowptr[u + 1] - hist->rowptr[u]);
-    for (int32_t r = 0; r < W->nrows; ++r) max_row = std::max<int64_t>(max_row, W->rowptr[r + 1] - W->rowptr[r]);
+    max_row = W.max_row;
     auto bits_for = [](int64_t v) { int b = 0; while ((int64_t(1) << b) <= v) ++b; return b; };
     bool key32 = bits_for(max_row) + bits_for(max_hist) <= 31;
     if (const char* e = std::getenv("SLIM_TOPN_KEY")) key32 = key32 && std::atoi(e) != 64;
@@ -578,7 +578,7 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
       if (v >= 64 && v <= max_cw && v % 64 == 0) cw = v;
     }
     const int nchunks = (ncols + cw - 1) / cw;
-    if (chunked && (size_t)W->nrows * ((size_t)nchunks + 1) * sizeof(uint32_t) > (size_t(2) << 30))
+    if (chunked && (size_t)W.nrows * ((size_t)nchunks + 1) * sizeof(uint32_t) > (size_t(2) << 30))
       chunked = false;
     if (kenv && std::strcmp(kenv, "chunk") == 0 && !chunked) {
       set_error("SLIMGPU_Predict: SLIM_TOPN_KERNEL=chunk needs nrcmds <= 64 and model rows sorted by id");
@@ -586,16 +586,16 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
     }
 
     if (chunked) {
-      DevBuf<uint32_t> d_split((size_t)std::max(W->nrows, 1) * ((size_t)nchunks + 1));
-      if (W->nrows > 0) {
-        const int64_t total = (int64_t)W->nrows * (nchunks + 1);
+      DevBuf<uint32_t> d_split((size_t)std::max(W.nrows, 1) * ((size_t)nchunks + 1));
+      if (W.nrows > 0) {
+        const int64_t total = (int64_t)W.nrows * (nchunks + 1);
         hipLaunchKernelGGL(k_row_split, dim3((unsigned)std::min<int64_t>((total + 255) / 256, prop.multiProcessorCount * 16)),
-                           dim3(256), 0, 0, W->nrows, nchunks, cw, d_wptr.p, d_wind.p, d_split.p);
+                           dim3(256), 0, 0, W.nrows, nchunks, cw, d_wptr.p, d_wind.p, d_split.p);
         TOPN_TRY(hipGetLastError());
       }
       TopN2Args T;
       T.nusers = nusers;
-      T.nitems_rows = W->nrows;
+      T.nitems_rows = W.nrows;
       T.ncols = ncols;
       T.nrcmds = nrcmds;
       T.cw = cw;
@@ -632,7 +632,7 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
       DevBuf<unsigned long long> d_disc((size_t)nwaves * ncols);
       TopNArgs T;
       T.nusers = nusers;
-      T.nitems_rows = W->nrows;
+      T.nitems_rows = W.nrows;
       T.ncols = ncols;
       T.nrcmds = nrcmds;
       T.wptr = d_wptr.p; T.wind = d_wind.p; T.wval = d_wval.p;
@@ -667,6 +667,42 @@ int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcm
   } catch (const std::bad_alloc&) {
     set_error("SLIMGPU_Predict: out of host memory");
     return SLIM_ERROR_MEMORY;
+  }
+}
+
+
+int32_t predict_device(const slim_csr_t* W, const slim_csr_t* hist, int32_t nrcmds,
+                       int32_t* output, float* scores, int32_t* counts) {
+  if (!W || !hist || !W->rowptr || !hist->rowptr || nrcmds < 1 || nrcmds > 128) {
+    set_error("SLIMGPU_Predict: bad arguments (1 <= nrcmds <= 128)");
+    return SLIM_ERROR_INPUT;
+  }
+  try {
+    (void)hipGetLastError();
+    int ndev = 0;
+    TOPN_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) throw HipFail{hipErrorNoDevice, "hipGetDeviceCount"};
+    const int64_t wnnz = W->rowptr[W->nrows];
+    DevBuf<int64_t> d_wptr((size_t)W->nrows + 1);
+    DevBuf<int32_t> d_wind((size_t)wnnz);
+    DevBuf<float> d_wval((size_t)wnnz);
+    TOPN_TRY(hipMemcpy(d_wptr.p, W->rowptr, sizeof(int64_t) * ((size_t)W->nrows + 1), hipMemcpyHostToDevice));
+    if (wnnz) {
+      TOPN_TRY(hipMemcpy(d_wind.p, W->rowind, sizeof(int32_t) * (size_t)wnnz, hipMemcpyHostToDevice));
+      TOPN_TRY(hipMemcpy(d_wval.p, W->rowval, sizeof(float) * (size_t)wnnz, hipMemcpyHostToDevice));
+    }
+    DeviceRowView v;
+    v.nrows = W->nrows;
+    v.ncols = W->ncols;
+    v.nnz = wnnz;
+    v.d_ptr = d_wptr.p;
+    v.d_ind = d_wind.p;
+    v.d_val = d_wval.p;
+    for (int32_t r = 0; r < W->nrows; ++r) v.max_row = std::max<int64_t>(v.max_row, W->rowptr[r + 1] - W->rowptr[r]);
+    return predict_device_view(v, hist, nrcmds, output, scores, counts);
+  } catch (const HipFail& e) {
+    set_error(std::string("SLIMGPU_Predict: HIP error '") + hipGetErrorString(e.code) + "' in " + e.where);
+    return e.code == hipErrorOutOfMemory ? SLIM_ERROR_MEMORY : SLIM_ERROR;
   }
 }
 

@@ -82,6 +82,44 @@ class ColumnStats(object):
             raise RuntimeError("SLIMGPU_LastColumnStats failed (%d)" % rc)
 
 
+class ResidentModel(object):
+    """A learned model that stays in HBM (SLIMGPU_LearnResident): both views on the device, usable as
+    the next solve's warm start without an upload; `fetch()` forms SLIM_Learn's host model."""
+
+    def __init__(self, lib, handle):
+        self._lib = lib
+        self.handle = C.c_void_p(handle)
+
+    @property
+    def nnz(self):
+        return int(self._lib.SLIMGPU_ModelNnz(self.handle))
+
+    def fetch_begin(self):
+        """Start the copy to the host on its own stream + host thread (runs beside the next solve)."""
+        st = self._lib.SLIMGPU_ModelFetchBegin(self.handle)
+        if st != SLIM_OK:
+            raise RuntimeError("SLIMGPU_ModelFetchBegin failed (%d): %s" % (st, _lib.last_error()))
+
+    def fetch(self, return_handle=False):
+        """The host model (joins a begun fetch): scipy CSC, or the slim_t handle (SLIM_FreeModel)."""
+        st = C.c_int32(0)
+        h = self._lib.SLIMGPU_ModelFetch(self.handle, C.byref(st))
+        if not h:
+            raise RuntimeError("SLIMGPU_ModelFetch failed (%d): %s" % (st.value, _lib.last_error()))
+        return h if return_handle else model_to_scipy(self._lib, h)
+
+    def free(self):
+        if self.handle:
+            self._lib.SLIMGPU_ModelFree(C.byref(self.handle))
+            self.handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 class DeviceMatrix(object):
     """Training matrix resident in HBM (CSR + column view + norms)."""
 
@@ -181,6 +219,20 @@ class DeviceMatrix(object):
         if return_handle:
             return h, stats.as_dict()
         return model_to_scipy(self._lib, h), stats.as_dict()
+
+    def learn_resident(self, warm=None, **opts):
+        """SLIMGPU_LearnResident: like learn(), but the model stays in HBM (ResidentModel); `warm`
+        is a ResidentModel of an earlier solve (no upload).  Returns (ResidentModel, stats dict)."""
+        iopt, dopt = make_options(**opts)
+        st = C.c_int32(0)
+        h = self._lib.SLIMGPU_LearnResident(self.handle, iopt.ctypes.data_as(C.c_void_p),
+                                            dopt.ctypes.data_as(C.c_void_p),
+                                            warm.handle if warm is not None else None, C.byref(st))
+        if not h:
+            raise RuntimeError("SLIMGPU_LearnResident failed (%d): %s" % (st.value, _lib.last_error()))
+        stats = _lib.Stats()
+        self._lib.SLIMGPU_LastStats(C.byref(stats))
+        return ResidentModel(self._lib, h), stats.as_dict()
 
     def column_stats(self):
         return ColumnStats(self._lib, self.ncols)

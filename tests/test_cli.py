@@ -152,3 +152,27 @@ def test_learn_admm_then_predict_ml100k(tmp_path):
             os.path.join(GOLDEN, "ml100k-test.csr"))
     hr = float(re.search(r"hr: (\S+)", q.stdout).group(1))
     assert 0.31 <= hr <= 0.34                                     # 0.3266 measured
+
+
+@pytest.mark.gpu
+def test_mselect_with_resident_models_prints_the_same_lines(tmp_path):
+    """slim_mselect keeps the grid's models in HBM (SLIMGPU_LearnResident / ModelPredict); with
+    SLIM_GPU_RESIDENT=0 every model is assembled on the host as before: the same lines (nnz, HR,
+    ARHR per pair), the same model files."""
+    l12 = str(tmp_path / "l12")
+    open(l12, "w").write("1.0 1.0\n2.0 1.0\n4.0 5.0\n0.5 5.0\n")
+    outs = []
+    for res in ("1", "0"):
+        d = tmp_path / ("res" + res)
+        d.mkdir()
+        env = dict(os.environ, SLIM_GPU_RESIDENT=res)
+        p = subprocess.run([os.path.join(BIN, "slim_mselect"), os.path.join(GOLDEN, "ml100k-train.csr"),
+                            os.path.join(GOLDEN, "ml100k-test.csr"), l12], capture_output=True,
+                           text=True, cwd=str(d), timeout=600, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        outs.append(re.findall(r"(l1r: \S+ l2r: \S+ nnz:\s+\d+ hr: \S+ hr_head: \S+ hr_tail: \S+ arhr: \S+)", p.stdout))
+        assert len(outs[-1]) == 4
+    assert outs[0] == outs[1]
+    for name in ("1.0 1.0.model", "0.5 5.0.model"):
+        a = open(str(tmp_path / "res1" / name)).read()
+        assert a == open(str(tmp_path / "res0" / name)).read() and len(a) > 1000

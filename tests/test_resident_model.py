@@ -1,0 +1,151 @@
+"""Models resident in HBM (SLIMGPU_LearnResident / ModelFetch, include/slim_gpu.h): the grid loop of
+src/programs/slim_mselect.c:94-113 without the model crossing PCIe twice per pair.  The bar: the fetched
+host model is SLIM_Learn's (SaveModel, estimate.c:570-593), both views, bit for bit -- on every solver
+path, cold and warm, with a fetch running beside the next solve, and when a column overflows its arena."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from slim_amd import _lib
+from slim_amd.engine import KERNEL_GRAM, KERNEL_TILE, KERNEL_WAVE_LDS, DeviceMatrix
+
+pytestmark = pytest.mark.gpu
+
+
+def views(lib, h):
+    """(colptr, colind, colval, rowptr, rowind, rowval) of a host model handle, copied."""
+    v = C.cast(h, C.POINTER(_lib.CsrView)).contents
+    n = int(v.ncols)
+    cp = np.ctypeslib.as_array(v.colptr, shape=(n + 1,)).copy()
+    rp = np.ctypeslib.as_array(v.rowptr, shape=(n + 1,)).copy()
+    nnz = int(cp[-1])
+    assert int(rp[-1]) == nnz
+
+    def arr(p):
+        return np.ctypeslib.as_array(p, shape=(nnz,)).copy() if nnz else np.zeros(0)
+    return cp, arr(v.colind), arr(v.colval), rp, arr(v.rowind), arr(v.rowval)
+
+
+def same_model(lib, ha, hb):
+    for a, b in zip(views(lib, ha), views(lib, hb)):
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+
+
+def free(lib, h):
+    lib.SLIM_FreeModel(C.byref(C.c_void_p(h)))
+
+
+def ratings(nrows, ncols, density, seed, binary):
+    rng = np.random.default_rng(seed)
+    R = sp.random(nrows, ncols, density=density, format="csr", random_state=rng, dtype=np.float32)
+    R.data[:] = 1.0 if binary else rng.integers(1, 6, R.nnz).astype(np.float32)
+    return R
+
+
+@pytest.mark.parametrize("kernel,shape,binary", [
+    (KERNEL_WAVE_LDS, (900, 300, 0.05), False),
+    (KERNEL_TILE, (30000, 700, 0.01), True),
+    (KERNEL_GRAM, (30000, 700, 0.01), True),     # byte planes
+    (KERNEL_GRAM, (20000, 500, 0.02), False),    # integer ratings
+])
+def test_resident_model_is_the_host_model_cold_and_warm(kernel, shape, binary):
+    R = ratings(*shape, seed=5, binary=binary)
+    mat = DeviceMatrix.from_scipy(R, binary=binary)
+    lib = mat._lib
+    kw = dict(optTol=1e-7, niters=200, seed=3, kernel=kernel)
+    h1, _ = mat.learn(return_handle=True, l1r=2.0, l2r=1.0, **kw)
+    d1, st = mat.learn_resident(l1r=2.0, l2r=1.0, **kw)
+    assert d1.nnz == st["nnzW"] > 0
+    f1 = d1.fetch(return_handle=True)
+    same_model(lib, h1, f1)
+    # warm: host handle vs resident model, then the next pair from each
+    h2, s2h = mat.learn(imodel=h1, return_handle=True, l1r=2.0, l2r=5.0, **kw)
+    d2, s2d = mat.learn_resident(warm=d1, l1r=2.0, l2r=5.0, **kw)
+    assert s2h["sweeps"] == s2d["sweeps"] and s2h["D"] == s2d["D"]
+    d2.fetch_begin()                       # copies while the next solve runs
+    d3, _ = mat.learn_resident(warm=d2, l1r=1.0, l2r=5.0, **kw)
+    f2 = d2.fetch(return_handle=True)
+    same_model(lib, h2, f2)
+    h3, _ = mat.learn(imodel=h2, return_handle=True, l1r=1.0, l2r=5.0, **kw)
+    f3 = d3.fetch(return_handle=True)
+    same_model(lib, h3, f3)
+    f3b = d3.fetch(return_handle=True)     # a second fetch copies again
+    same_model(lib, f3, f3b)
+    for h in (h1, h2, h3, f1, f2, f3, f3b):
+        free(lib, h)
+    for d in (d1, d2, d3):
+        d.free()
+    assert d1.nnz == -1
+
+
+def test_resident_model_when_a_column_overflows_its_arena(monkeypatch):
+    R = ratings(20000, 400, 0.02, seed=9, binary=True)
+    mat = DeviceMatrix.from_scipy(R, binary=True)
+    lib = mat._lib
+    kw = dict(l1r=0.5, l2r=1.0, optTol=1e-7, niters=100, seed=1, kernel=KERNEL_TILE)
+    _, st = mat.learn(**kw)
+    # a third of what the model needs: both solves re-solve the overflowed columns in further launches
+    # (a retry regroups the tiles, so it is compared with a host solve under the same arena)
+    monkeypatch.setenv("SLIM_GPU_ARENA", str(max(1024, int(st["nnzW"]) // 3)))
+    h, _ = mat.learn(return_handle=True, **kw)
+    d, _ = mat.learn_resident(**kw)
+    f = d.fetch(return_handle=True)
+    same_model(lib, h, f)
+    free(lib, h), free(lib, f)
+
+
+def test_resident_model_errors():
+    R = ratings(2000, 200, 0.05, seed=2, binary=True)
+    mat = DeviceMatrix.from_scipy(R, binary=True)
+    lib = mat._lib
+    st = C.c_int32(0)
+    assert not lib.SLIMGPU_ModelFetch(None, C.byref(st)) and st.value != 0
+    assert lib.SLIMGPU_ModelFetchBegin(None) != 0
+    lib.SLIMGPU_ModelFree(C.byref(C.c_void_p(None)))   # no-op
+    d, _ = mat.learn_resident(l1r=1.0, l2r=1.0)
+    W = d.fetch()
+    W2, _ = mat.learn(l1r=1.0, l2r=1.0)
+    assert abs(W - W2).nnz == 0 or abs(W - W2).max() == 0
+
+
+def test_gram_builder_in_user_passes_forms_the_same_G(monkeypatch):
+    """G = R^T R of a binary matrix with more users than 32 cluster members hold as one word each in
+    LDS (C5: 10M users) is formed in user passes (engine.hip: gram_passes) -- the same G, hence the
+    same item-space models bit for bit, as the single-launch form and as the line-gathering form."""
+    R = ratings(40000, 600, 0.01, seed=11, binary=True)
+    kw = dict(l1r=1.0, l2r=1.0, optTol=1e-7, niters=100, seed=1, kernel=KERNEL_GRAM)
+    W0, s0 = DeviceMatrix.from_scipy(R, binary=True).learn(**kw)          # one launch, words in LDS
+    monkeypatch.setenv("SLIM_GPU_TEST_HOOKS", "1")
+    monkeypatch.setenv("SLIM_GPU_TEST_GBITS_ROWS", "300")                 # 1250 users per member -> 5 passes
+    W1, s1 = DeviceMatrix.from_scipy(R, binary=True).learn(**kw)
+    monkeypatch.delenv("SLIM_GPU_TEST_GBITS_ROWS")
+    monkeypatch.setenv("SLIM_GPU_NO_GBITS", "1")                          # the line-gathering builder
+    W2, s2 = DeviceMatrix.from_scipy(R, binary=True).learn(**kw)
+    assert s0["nnzW"] == s1["nnzW"] == s2["nnzW"] > 0
+    assert abs(W0 - W1).nnz == 0 and abs(W0 - W2).nnz == 0
+    assert s0["sweeps"] == s1["sweeps"] == s2["sweeps"]
+
+
+def test_predict_through_a_resident_model_equals_predict_on_the_fetched_one():
+    R = ratings(3000, 400, 0.03, seed=4, binary=False)
+    mat = DeviceMatrix.from_scipy(R)
+    lib = mat._lib
+    d, _ = mat.learn_resident(l1r=1.0, l2r=2.0)
+    h = d.fetch(return_handle=True)
+    Rc = sp.csr_matrix(R)
+    ptr = np.ascontiguousarray(Rc.indptr, dtype=np.intp)
+    ind = np.ascontiguousarray(Rc.indices, dtype=np.int32)
+    val = np.ascontiguousarray(Rc.data, dtype=np.float32)
+    trn = C.c_void_p()
+    assert lib.Py_csr_wrapper(Rc.shape[0], ptr, ind, val.ctypes.data_as(C.c_void_p), C.byref(trn)) == 0
+    n = 10
+    out = [np.full(Rc.shape[0] * n, -1, np.int32) for _ in range(2)]
+    sc = [np.zeros(Rc.shape[0] * n, np.float32) for _ in range(2)]
+    assert lib.SLIMGPU_ModelPredict(n, d.handle, trn, out[0].ctypes.data_as(C.c_void_p),
+                                    sc[0].ctypes.data_as(C.c_void_p)) == 0
+    assert lib.SLIMGPU_Predict(n, C.c_void_p(h), trn, out[1], sc[1]) == 0
+    assert np.array_equal(out[0], out[1]) and np.array_equal(sc[0], sc[1]) and (out[0] >= 0).any()
+    free(lib, h)
