@@ -10,6 +10,7 @@ import pytest
 import scipy.sparse as sp
 
 from slim_amd import _lib
+from slim_amd.constants import SLIM_ERROR_INPUT, SLIM_OK
 from slim_amd.engine import KERNEL_GRAM, KERNEL_TILE, KERNEL_WAVE_LDS, DeviceMatrix
 
 pytestmark = pytest.mark.gpu
@@ -90,7 +91,7 @@ def test_resident_model_when_a_column_overflows_its_arena(monkeypatch):
     R = ratings(20000, 400, 0.02, seed=9, binary=True)
     mat = DeviceMatrix.from_scipy(R, binary=True)
     lib = mat._lib
-    kw = dict(l1r=0.5, l2r=1.0, optTol=1e-7, niters=100, seed=1, kernel=KERNEL_TILE)
+    kw = dict(l1r=0.5, l2r=1.0, optTol=1e-11, niters=2000, seed=1, kernel=KERNEL_TILE)   # (tight: two tile groupings)
     W, st = mat.learn(**kw)
     monkeypatch.setenv("SLIM_GPU_ARENA", str(max(1024, int(st["nnzW"]) // 3)))
     d, st2 = mat.learn_resident(**kw)
@@ -114,8 +115,8 @@ def test_resident_model_errors():
     mat = DeviceMatrix.from_scipy(R, binary=True)
     lib = mat._lib
     st = C.c_int32(0)
-    assert not lib.SLIMGPU_ModelFetch(None, C.byref(st)) and st.value != 0
-    assert lib.SLIMGPU_ModelFetchBegin(None) != 0
+    assert not lib.SLIMGPU_ModelFetch(None, C.byref(st)) and st.value == SLIM_ERROR_INPUT
+    assert lib.SLIMGPU_ModelFetchBegin(None) == SLIM_ERROR_INPUT
     lib.SLIMGPU_ModelFree(C.byref(C.c_void_p(None)))   # no-op
     d, _ = mat.learn_resident(l1r=1.0, l2r=1.0)
     W = d.fetch()
@@ -152,12 +153,12 @@ def test_predict_through_a_resident_model_equals_predict_on_the_fetched_one():
     ind = np.ascontiguousarray(Rc.indices, dtype=np.int32)
     val = np.ascontiguousarray(Rc.data, dtype=np.float32)
     trn = C.c_void_p()
-    assert lib.Py_csr_wrapper(Rc.shape[0], ptr, ind, val.ctypes.data_as(C.c_void_p), C.byref(trn)) == 0
+    assert lib.Py_csr_wrapper(Rc.shape[0], ptr, ind, val.ctypes.data_as(C.c_void_p), C.byref(trn)) == SLIM_OK
     n = 10
     out = [np.full(Rc.shape[0] * n, -1, np.int32) for _ in range(2)]
     sc = [np.zeros(Rc.shape[0] * n, np.float32) for _ in range(2)]
     assert lib.SLIMGPU_ModelPredict(n, d.handle, trn, out[0].ctypes.data_as(C.c_void_p),
-                                    sc[0].ctypes.data_as(C.c_void_p)) == 0
-    assert lib.SLIMGPU_Predict(n, C.c_void_p(h), trn, out[1], sc[1]) == 0
+                                    sc[0].ctypes.data_as(C.c_void_p)) == SLIM_OK
+    assert lib.SLIMGPU_Predict(n, C.c_void_p(h), trn, out[1], sc[1]) == SLIM_OK
     assert np.array_equal(out[0], out[1]) and np.array_equal(sc[0], sc[1]) and (out[0] >= 0).any()
     free(lib, h)
