@@ -628,6 +628,31 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       }
     };
     warm_x();
+    // -- g carried over from the previous solve of this problem (a grid step that only moved l2:
+    //    same active set, x starts at that solve's model): what the set-up row and the fold below
+    //    would recompute -- aTy - sum_j x_j G[j, :] over exactly the kept coefficients (the epsilon
+    //    rule of cd.c:27 governs both) -- is what that solve held on chip when it stopped.  Saved and
+    //    reloaded in the threads' own layout (16 floats per thread and group), slot `item`.
+    // (instantiations of up to six groups -- the grids' shapes; the 13-group kernel keeps its register budget)
+    constexpr bool kCarry = K <= kGramrCarryMaxGroups;
+    const bool carried = kCarry && S.g_load != nullptr;
+    if (carried) {
+      const float4* __restrict__ gs = reinterpret_cast<const float4*>(S.g_load + (int64_t)item * S.g_stride);
+      static_for<KRA>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        gramr_v16 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 q = gs[(k * NT + tid) * 4 + j];
+          v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+        }
+        gramr_reg<k>(gr) = v;
+      });
+#pragma unroll
+      for (int k = 0; k < KL; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gl4[(k * 4 + j) * NT + tid] = gs[((KRA + k) * NT + tid) * 4 + j];
+    } else {
     static_for<KRA>([&](auto kc) __attribute__((always_inline)) {
       gramr_reg<decltype(kc)::value>(gr) = (gramr_v16)(0.0f);
     });
@@ -635,6 +660,7 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
     for (int k = 0; k < KL; ++k)
 #pragma unroll
       for (int j = 0; j < 4; ++j) gl4[(k * 4 + j) * NT + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
 
     int maxit = 0;
@@ -658,7 +684,8 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       s_reg[lane] = 0.0;
     }
     int phase = 0;
-    bool init_row = true;
+    bool init_row = !carried;
+    if (carried) fe = we;  // (nothing to fold: phase 0 applies no row)
     int t = 0, p0 = 0;      // sweep, first position of the batch
     float dlt = 0.0f;
     PermCtx pc = perm_make(1u, 0u);
@@ -941,6 +968,21 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
       wpos = 0;
       if (ncols <= 0) break;
     }
+    // g as this solve leaves it, for the next solve of the problem to start from (see above)
+    if (kCarry && S.g_save != nullptr) {
+      float4* __restrict__ gs = reinterpret_cast<float4*>(S.g_save + (int64_t)item * S.g_stride);
+      static_for<KRA>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        const gramr_v16 v = gramr_reg<k>(gr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          gs[(k * NT + tid) * 4 + j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+      });
+#pragma unroll
+      for (int k = 0; k < KL; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gs[((KRA + k) * NT + tid) * 4 + j] = gl4[(k * 4 + j) * NT + tid];
+    }
     // ||y - A x||^2 = |a_iC|^2 - sum_i x_i (aTy_i + g_i) over the kept coefficients (every
     // wavefront formed the same sums; wavefront 0 reports)
     if (wave == 0) {
@@ -967,7 +1009,8 @@ __global__ __launch_bounds__(kGramrNT, WPS) void cd_gramr_kernel(
         S.st_D[item] = (int64_t)s_D * (int64_t)(conv ? niters : maxit);  // (sweeps that ran)
         S.st_U[item] = (int64_t)Uu;
         S.st_G[item] = nrows_read;  // (the engine reports the staging pass's G for the column)
-        S.st_B[item] = (int64_t)nrows_read * (P.ldb + 16 * (int64_t)(nchunks < NT ? nchunks : NT)) + (int64_t)nhi16_read * 16;
+        S.st_B[item] = (int64_t)nrows_read * (P.ldb + 16 * (int64_t)(nchunks < NT ? nchunks : NT)) + (int64_t)nhi16_read * 16 +
+                       ((carried ? 4 : 0) + (kCarry && S.g_save != nullptr ? 4 : 0)) * S.g_stride;  // (+ g carried in / out)
 #endif
         S.st_err[item] = err;
         S.st_obj[item] = err + (float)reg;

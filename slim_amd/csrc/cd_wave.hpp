@@ -120,6 +120,12 @@ struct SolveArgs {
                                  // user passes, the passes' common table: the launch's ubounds / csplit point at
                                  // the pass's first range)
   int32_t gram_accum;            // gram_bits, user passes after the first: the sums are ADDED to G
+  // packed item-space kernel (cd_gramr.hpp): g of every problem as the solve leaves it (g_save) / as an
+  // earlier solve of the same problems left it (g_load: starts from it instead of set-up row + fold);
+  // [item][g_stride] floats in the kernel's own thread layout; both may point at the same buffer
+  float* g_save;
+  const float* g_load;
+  int64_t g_stride;
   // output arena: column iC's kept entries land at [out_off[iC], +out_cnt[iC])
   int32_t* out_cnt;
   int64_t* out_off;

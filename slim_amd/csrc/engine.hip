@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -33,7 +34,13 @@
 #include "host_csr.hpp"
 
 // ---- the opaque handle ---------------------------------------------------------
+inline uint64_t slimgpu_next_uid() {
+  static std::atomic<uint64_t> n{0};
+  return ++n;
+}
+
 struct slimgpu_matrix {
+  const uint64_t uid = slimgpu_next_uid();  // (a handle's identity beyond its address)
   int device = 0;
   hipStream_t stream = nullptr;
   int32_t nrows = 0, ncols = 0;
@@ -113,6 +120,15 @@ struct slimgpu_model {
   int64_t* d_rowptr = nullptr;
   int32_t* d_rowind = nullptr;
   float* d_rowval = nullptr;
+  // g of every problem as the solve that produced this model left it (cd_gramr.hpp, g_save): the
+  // next solve of the same problems on the same handle starts from it when only l2 moved (the same
+  // l1 = the same active sets) instead of re-folding this model into g row by row.  The buffer travels
+  // down the chain of a grid's models (the next solve updates it in place and takes it over).
+  mutable float* d_gsave = nullptr;
+  mutable bool gsave_valid = false;
+  int64_t gsave_stride = 0;
+  double gsave_l1 = 0;
+  uint64_t gsave_owner = 0;  // uid of the matrix handle
   // a fetch to the host running beside the next solve (model_fetch_begin)
   std::thread fetcher;
   bool fetch_begun = false;
@@ -1702,6 +1718,33 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
     }
 
     bool cluster_fallback = false;
+    // g carried between the solves of a grid (slimgpu_model::d_gsave): all columns of an unsharded
+    // solve on the packed kernel, the model staying in HBM
+    float* carry_buf = nullptr;
+    int64_t carry_stride = 0;
+    bool carry_from_warm = false;
+    if (resident && use_gramr && std::max(gramr_kr, 1) + gramr_kl <= kGramrCarryMaxGroups && !columns && nwork == ncols &&
+        opt.shard_count == 1 && !std::getenv("SLIM_GPU_NO_CARRY")) {
+      carry_stride = (int64_t)(std::max(gramr_kr, 1) + gramr_kl) * 8192;
+      const size_t carry_bytes = sizeof(float) * (size_t)ncols * (size_t)carry_stride;
+      if (warm_dev && warm_dev->d_gsave && warm_dev->gsave_owner == m->uid && warm_dev->gsave_stride == carry_stride &&
+          warm_dev->n == ncols) {
+        // the previous model's buffer: read where l1 is the same, overwritten in place either way, and
+        // no longer that model's from here on (a failure below leaves nothing half-valid behind)
+        carry_from_warm = warm_dev->gsave_valid && warm_dev->gsave_l1 == opt.l1r;
+        carry_buf = warm_dev->d_gsave;
+        warm_dev->d_gsave = nullptr;
+        warm_dev->gsave_valid = false;
+      } else {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (carry_bytes <= (size_t(8) << 30) && carry_bytes * 4 <= free_b) carry_buf = dev_alloc<float>((size_t)ncols * (size_t)carry_stride);
+      }
+    }
+    struct CarryGuard {  // (freed unless a model takes it over)
+      float*& p;
+      ~CarryGuard() { if (p) (void)hipFree(p); }
+    } carry_guard{carry_buf};
     for (int attempt = 0; attempt < 8 && !pending.empty(); ++attempt) {
       const int32_t npend = (int32_t)pending.size();
       int32_t* d_ai = ws_get<int32_t>(m->ws_arena_i, (size_t)arena_cap, m);
@@ -1778,6 +1821,15 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       if (const char* e = std::getenv("SLIM_GPU_GBITS"); e && S.gram_bits) S.gram_bits = std::atoi(e) == 1 ? 1 : 2;
       S.gram_split_stride = clusterK + 1;
       S.gram_accum = 0;
+      S.g_save = nullptr;
+      S.g_load = nullptr;
+      S.g_stride = 0;
+      if (carry_buf) {  // (resident models on the packed kernel: g carried from pair to pair, see slimgpu_model)
+        S.g_save = carry_buf;
+        S.g_stride = carry_stride;
+        // (a retry re-solves a column whose slot already holds this solve's result: it folds again)
+        S.g_load = (carry_from_warm && attempt == 0) ? carry_buf : nullptr;
+      }
       if (gram_passes > 1) {
         if (S.gram_bits) {  // pass gram_pass of gram_passes: this launch's 32 user ranges
           S.ubounds = m->d_gubounds + 32 * gram_pass;
@@ -2125,6 +2177,14 @@ slim_csr_t* learn_cd(slimgpu_matrix_t* m, const LearnOptions& opt, const slim_cs
       HIP_TRY(hipStreamSynchronize(stream));
       if (cat_i) (void)hipFree(cat_i);
       if (cat_v) (void)hipFree(cat_v);
+      if (carry_buf) {
+        dm->d_gsave = carry_buf;
+        dm->gsave_valid = true;
+        dm->gsave_stride = carry_stride;
+        dm->gsave_l1 = opt.l1r;
+        dm->gsave_owner = m->uid;
+        carry_buf = nullptr;  // (the model's now)
+      }
       *rio->out = dm.release();
     } else {
     colptr = static_cast<ssize_t*>(std::malloc(sizeof(ssize_t) * ((size_t)ncols + 1)));
@@ -2400,6 +2460,7 @@ void model_free(slimgpu_model* w) {
   (void)hipSetDevice(w->device);
   (void)hipFree(w->d_colptr); (void)hipFree(w->d_colind); (void)hipFree(w->d_colval);
   (void)hipFree(w->d_rowptr); (void)hipFree(w->d_rowind); (void)hipFree(w->d_rowval);
+  (void)hipFree(w->d_gsave);
   delete w;
 }
 

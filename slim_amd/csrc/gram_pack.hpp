@@ -43,6 +43,7 @@ namespace slimamd {
 constexpr int kGramrNT = 512;     // threads of cd_gramr.hpp's workgroup
 constexpr int kPackGroup = 8192;  // ranks per group: 512 threads x one 16-byte load
 constexpr int kGramrMaxGroups = 13;  // groups of the largest instantiation, cd_gramr_kernel<10, 3>: 106 496 items
+constexpr int kGramrCarryMaxGroups = 6;  // instantiations that can carry g from solve to solve (cd_gramr.hpp, g_save / g_load)
 
 struct GramPacked {
   const uint8_t* lo;       // [ncols][ldb]

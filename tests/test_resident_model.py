@@ -52,7 +52,10 @@ def ratings(nrows, ncols, density, seed, binary):
     (KERNEL_GRAM, (30000, 700, 0.01), True),     # byte planes
     (KERNEL_GRAM, (20000, 500, 0.02), False),    # integer ratings
 ])
-def test_resident_model_is_the_host_model_cold_and_warm(kernel, shape, binary):
+def test_resident_model_is_the_host_model_cold_and_warm(kernel, shape, binary, monkeypatch):
+    # (a warm step from a resident model may start from the g the previous solve left instead of folding
+    # the model again -- rounding-level differences, tested below; here the fold, which is SLIM_Learn's)
+    monkeypatch.setenv("SLIM_GPU_NO_CARRY", "1")
     R = ratings(*shape, seed=5, binary=binary)
     mat = DeviceMatrix.from_scipy(R, binary=binary)
     lib = mat._lib
@@ -162,3 +165,39 @@ def test_predict_through_a_resident_model_equals_predict_on_the_fetched_one():
     assert lib.SLIMGPU_Predict(n, C.c_void_p(h), trn, out[1], sc[1]) == SLIM_OK
     assert np.array_equal(out[0], out[1]) and np.array_equal(sc[0], sc[1]) and (out[0] >= 0).any()
     free(lib, h)
+
+
+def test_g_carried_from_pair_to_pair_gives_the_folded_models(monkeypatch):
+    """A grid step that only moves l2 starts from the g the previous solve left on chip (cd_gramr.hpp:
+    g_save / g_load) instead of folding the previous model into g row by row (cd.c:108-110 in item
+    space) -- the same quantity up to fp32 rounding: the models of a chain of pairs agree with the
+    folded chain's to the parity tolerance, with the same sweep counts; a step that moves l1 folds."""
+    R = ratings(30000, 700, 0.01, seed=21, binary=True)
+    chain = [(2.0, 1.0), (2.0, 3.0), (2.0, 0.5), (1.0, 0.5), (1.0, 2.0)]
+    kw = dict(optTol=1e-7, niters=300, seed=3, kernel=KERNEL_GRAM)
+
+    def run(carry):
+        if carry:
+            monkeypatch.delenv("SLIM_GPU_NO_CARRY", raising=False)
+        else:
+            monkeypatch.setenv("SLIM_GPU_NO_CARRY", "1")
+        mat = DeviceMatrix.from_scipy(R, binary=True)
+        prev, out = None, []
+        for l1, l2 in chain:
+            cur, st = mat.learn_resident(warm=prev, l1r=l1, l2r=l2, **kw)
+            out.append((cur.fetch(), st["sweeps"], st["gram_rows"]))
+            if prev is not None:
+                prev.free()
+            prev = cur
+        return out
+    folded, carried = run(False), run(True)
+    for k, ((Wf, sf, rf), (Wc, sc, rc)) in enumerate(zip(folded, carried)):
+        d = abs(Wf - Wc)
+        assert (d.max() if d.nnz else 0.0) <= 2e-5, k
+        assert abs(sf - sc) <= 0.01 * sf
+        if k in (1, 2, 4):     # only l2 moved: the rows of the fold (one per kept coefficient) are not read
+            assert rc <= rf - int(0.9 * folded[k - 1][0].nnz)
+        elif k == 0:           # the cold pair streams what the folded chain's streams
+            assert rc == rf
+        else:                  # l1 moved: folds like the other chain (from a model a rounding apart)
+            assert abs(rc - rf) <= 0.01 * rf
