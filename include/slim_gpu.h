@@ -213,7 +213,10 @@ slim_t *SLIMGPU_LearnColumns(slimgpu_matrix_t *mat, int32_t ncolumns,
  * start from such a model without an upload; SLIMGPU_ModelFetch forms the host model of SLIM_Learn
  * (the same arrays, bit for bit; SLIM_FreeModel releases it) when the caller wants it, and
  * SLIMGPU_ModelFetchBegin starts that copy on its own stream and host thread so that it runs beside
- * the next solve (ModelFetch then joins it).  One device per model (ngpus = 1). */
+ * the next solve (ModelFetch then joins it).  One device per model (ngpus = 1).
+ * A warm start from a resident model that keeps l1 (a grid step along l2: the same active sets) on the
+ * packed item-space kernel does not fold the model into g again: it starts from the g the previous
+ * solve left (the same quantity, cd.c:108-110, at fp32-rounding distance; SLIM_GPU_NO_CARRY=1 folds). */
 typedef struct slimgpu_model slimgpu_model_t;
 slimgpu_model_t *SLIMGPU_LearnResident(slimgpu_matrix_t *mat, int32_t *ioptions, double *doptions,
                                        const slimgpu_model_t *warm, int32_t *r_status);
