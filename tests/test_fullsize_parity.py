@@ -202,3 +202,50 @@ def test_c5_full_size_warm_started_grid_steps_match_oracle():
         prev_g, prev_o = W, Wo
     O.cache_setup(False)
     mat.close()
+
+
+@pytest.mark.timeout(900, method="thread")
+def test_c5_full_size_grid_step_from_the_carried_g_matches_oracle():
+    """The grid as Py_SLIM_Mselect runs it since round 6: ALL 20 000 columns of the 10M x 20K matrix per
+    pair, the models resident in HBM (SLIMGPU_LearnResident), and the second pair -- an l2 step -- started
+    from the g the first solve left on chip instead of folding the model again (cd_gramr.hpp: g_load).
+    One whole tile of that launch (the median of its work list, keyed by its position) against the
+    oracle walking that tile in the same visiting order, cold and warm-started from ITS previous model
+    (estimate.c:453-464, cd.c:108-110: the fold the engine skipped): <= 2e-5, identical active sets and
+    sweep counts; and the carried solve streams no fold rows."""
+    import os
+    mat, R = _stage("c5")
+    threads = min(32, O.max_threads())
+    order = _batch_tiles(mat, 0, mat.ncols)         # the engine's work list of an all-column solve
+    k = len(order) // 2
+    tile = order[k]
+    pairs = [tuple(map(float, ln.split())) for ln in
+             open(os.path.join(os.path.dirname(__file__), "golden", "l12file")) if ln.strip()]
+    assert pairs[0] == (0.1, 0.1) and pairs[1] == (0.1, 0.5)
+    mat.expect_solves(len(pairs))
+    O.cache_setup(True)
+    prev_d = prev_o = None
+    rows = []
+    for step, (l1, l2) in enumerate(pairs[:2]):
+        kw = dict(l1r=l1, l2r=l2, optTol=1e-7)
+        cur, st = mat.learn_resident(warm=prev_d, niters=10000, seed=1, **kw)
+        assert st["kernel"] == KERNEL_GRAM
+        cs = mat.column_stats()
+        W = cur.fetch()
+        rows.append(int(st["gram_rows"]))
+        Wo, so, _, _ = O.learn_cd_tile(R, tileP=32, order=order.reshape(-1), tiles=(k, 1), maxniters=10000,
+                                       seed=1, nthreads=threads, binary=True, return_stats=True,
+                                       imodel=prev_o, **kw)
+        assert W[:, tile].nnz > 0
+        assert np.array_equal(cs.nacols[tile], so["nacols"][tile])
+        assert (cs.sweeps[tile] == so["sweeps"][tile]).mean() >= 0.98
+        assert maxdiff(W[:, tile], Wo[:, tile]) <= 2e-5
+        if prev_d is not None:
+            prev_d.free()
+        prev_d, prev_o = cur, Wo
+        if step == 1:
+            assert cs.sweeps[tile].max() <= 2
+            # one row of G per coefficient that moved, none for the fold (the folded step reads ~2 per coefficient)
+            assert rows[1] <= 1.1 * W.nnz
+    O.cache_setup(False)
+    mat.close()
