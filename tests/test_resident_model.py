@@ -201,3 +201,52 @@ def test_g_carried_from_pair_to_pair_gives_the_folded_models(monkeypatch):
             assert rc == rf
         else:                  # l1 moved: folds like the other chain (from a model a rounding apart)
             assert abs(rc - rf) <= 0.01 * rf
+
+
+def test_mselect_on_the_item_space_path_with_resident_models_and_the_carried_g(monkeypatch, capfd):
+    """Py_SLIM_Mselect end to end on a matrix the engine solves in item space (the grid announced): the
+    models stay in HBM, the l2 steps start from the carried g, top-N lists come from the resident row
+    view.  Against the same grid with host models (SLIM_GPU_RESIDENT=0: SLIM_Learn + Py_SLIM_Predict per
+    pair): the same best cells, HR / ARHR to 1e-3 (a list can change where two scores are a rounding
+    apart), nnz of every pair within 0.1 %."""
+    import re
+    from slim_amd import SLIM, SLIMatrix
+    rng = np.random.default_rng(31)
+    R = sp.random(40000, 2500, density=0.01, format="csr", random_state=rng, dtype=np.float32)
+    R.data[:] = 1.0
+    R.sort_indices()
+    # leave one rating per user out (users with at least two)
+    trn, tst = R.tolil(copy=True), sp.lil_matrix(R.shape, dtype=np.float32)
+    for u in range(R.shape[0]):
+        cols = R.indices[R.indptr[u]:R.indptr[u + 1]]
+        if cols.size >= 2:
+            j = int(cols[rng.integers(cols.size)])
+            trn[u, j] = 0
+            tst[u, j] = 1.0
+    trn, tst = sp.csr_matrix(trn), sp.csr_matrix(tst)
+    trn.eliminate_zeros()
+    params = {"dbglvl": 0, "algo": "cd", "nthreads": 1, "optTol": 1e-7, "niters": 200}
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SLIM_GPU_RESIDENT", mode)
+        trainmat = SLIMatrix(trn)
+        valmat = SLIMatrix(tst, trainmat)
+        model = SLIM()
+        capfd.readouterr()
+        model.mselect(params, trainmat, valmat, [1.0, 2.0], [1.0, 5.0, 10.0], nrcmds=10)
+        C.CDLL(None).fflush(None)            # (the library prints through libc's buffered stdout)
+        out = capfd.readouterr().out
+        lines = re.findall(r"l1r: (\S+) l2r: (\S+) nnz:\s+(\d+) hr: (\S+) hr_head: \S+ hr_tail: \S+ arhr: (\S+)", out)
+        assert len(lines) == 6
+        st = _lib.Stats()
+        model._lib.SLIMGPU_LastStats(C.byref(st))
+        res[mode] = (model.mselect_result, lines, st.kernel, st.gram_rows, st.nnzW)
+    (ra, la, ka, rows_a, nnz_a), (rb, lb, kb, rows_b, nnz_b) = res["1"], res["0"]
+    assert ka == kb == KERNEL_GRAM
+    assert ra["bestHR"][:2] == rb["bestHR"][:2] and ra["bestAR"][:2] == rb["bestAR"][:2]
+    for x, y in zip(la, lb):
+        assert x[:2] == y[:2] and abs(int(x[2]) - int(y[2])) <= 1e-3 * int(y[2])
+        assert abs(float(x[3]) - float(y[3])) <= 1e-3 and abs(float(x[4]) - float(y[4])) <= 1e-3
+    # the last pair is an l2 step: folded, it reads a row per coefficient of the previous model before its
+    # sweeps; from the carried g only the sweeps' rows
+    assert rows_b - rows_a >= 0.95 * int(lb[4][2]) and rows_a < rows_b
