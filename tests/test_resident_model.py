@@ -232,6 +232,7 @@ def test_mselect_on_the_item_space_path_with_resident_models_and_the_carried_g(m
         trainmat = SLIMatrix(trn)
         valmat = SLIMatrix(tst, trainmat)
         model = SLIM()
+        C.CDLL(None).fflush(None)            # (whatever earlier tests left in libc's buffer is not this grid's)
         capfd.readouterr()
         model.mselect(params, trainmat, valmat, [1.0, 2.0], [1.0, 5.0, 10.0], nrcmds=10)
         C.CDLL(None).fflush(None)            # (the library prints through libc's buffered stdout)
