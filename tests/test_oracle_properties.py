@@ -201,3 +201,87 @@ def test_item_space_restatement_walks_to_the_same_model():
     d = abs(sp.csc_matrix(W) - Wo)
     assert Wo.nnz > 500 and (d.max() if d.nnz else 0.0) <= 2e-7
     assert (sweeps == so["sweeps"]).mean() >= 0.98
+
+
+def test_item_space_grid_step_from_the_carried_g_is_the_warm_started_walk():
+    """The algebra of the carried g (cd_gramr.hpp: g_save / g_load), on the CPU in fp64
+    and independently of any GPU code.  A grid step that only moves l2 keeps every active set (the
+    screen aTy > l1 does not see l2), so the warm start of the reference -- x from the previous model,
+    y-hat = A x folded in before the first sweep (estimate.c:453-464, cd.c:108-110) -- is, in item space,
+    g = aTy - sum_j x_j G[j, :] over the kept coefficients: exactly the g the previous walk ends with
+    (the epsilon rule of cd.c:27 governs what enters g, what is folded and what is kept alike).  A numpy
+    walk that carries g and the full x across the step reaches the oracle's warm-started tile walk
+    (user space; ITS previous model) to the last float, with the same sweep counts; and its carried g
+    equals the recomputed fold."""
+    rng = np.random.default_rng(11)
+    R = sp.random(500, 64, density=0.15, format="csr", random_state=rng, dtype=np.float32)
+    R.data[:] = 1.0
+    R.sort_indices()
+    l1, tol, seed, eps = 0.5, 1e-10, 3, 1e-7
+    order = O.tile_work_order(R)
+    L = O.lib()
+    A = R.toarray().astype(np.float64)
+    G = A.T @ A
+    ncols = R.shape[1]
+    nnz_col = np.diff(R.tocsc().indptr)
+    cn = np.sqrt(np.diag(G).astype(np.float32)).astype(np.float32).astype(np.float64)
+
+    def walk(l2, state):
+        """one pair over every tile; state[iC] = (x, g) of the previous pair (None: cold)"""
+        W = np.zeros((ncols, ncols), np.float32)
+        sweeps = np.zeros(ncols, np.int32)
+        out = {}
+        for grp in range((order.size + 31) // 32):
+            members = [int(c) for c in order[grp * 32:(grp + 1) * 32]]
+            aty = {iC: G[:, iC].astype(np.float32).astype(np.float64) for iC in members}
+            act = {iC: (aty[iC] > l1) & (np.arange(ncols) != iC) for iC in members}
+            union = np.flatnonzero(np.any([act[iC] for iC in members], axis=0))
+            nu = union.size
+            for iC in members:
+                if state is None:
+                    x, gvec = np.zeros(ncols), aty[iC].copy()
+                else:
+                    xp, gp = state[iC]
+                    # what SLIM_Learn's warm start would form from the MODEL of the previous pair
+                    xm = np.where(np.abs(xp) > eps, xp.astype(np.float32).astype(np.float64), 0.0)
+                    xm = np.where(act[iC], np.maximum(xm, 0.0), 0.0)
+                    fold = aty[iC] - G @ xm
+                    x, gvec = xm.copy(), gp.copy()      # the carried g in place of the fold ...
+                    assert np.abs(gvec - fold).max() <= 1e-6 * max(1.0, np.abs(fold).max())   # ... which it equals
+                maxit = min(50 * int(nnz_col[iC]), 10000)
+                t, dlt = 0, 0.0
+                while t < maxit:
+                    key = L.oracle_perm_key(seed, grp, t)
+                    dlt = 0.0
+                    for p in range(nu):
+                        i = int(union[L.oracle_perm_index(p, nu, key)])
+                        if not act[iC][i]:
+                            continue
+                        xi = x[i]
+                        xeff = xi if abs(xi) > eps else 0.0
+                        num = gvec[i] + xeff * G[i, i]
+                        nx = (num - l1) / (cn[i] * cn[i] + l2) if num > l1 else 0.0
+                        neff = nx if abs(nx) > eps else 0.0
+                        if neff != xeff:
+                            gvec -= (neff - xeff) * G[i, :]
+                        x[i] = nx
+                        dlt += (nx - xi) ** 2
+                    t += 1
+                    if dlt < tol:
+                        break
+                sweeps[iC] = t if (t < maxit or dlt < tol) else maxit + 1
+                keep = np.abs(x) > eps
+                W[keep, iC] = x[keep].astype(np.float32)
+                out[iC] = (x, gvec)
+        return sp.csc_matrix(W), sweeps, out
+
+    W1, s1, st1 = walk(1.0, None)
+    W2, s2, _ = walk(4.0, st1)
+    Wo1, so1, _, _ = O.learn_cd_tile(R, tileP=32, order=order, l1r=l1, l2r=1.0, optTol=tol, seed=seed,
+                                     binary=True, return_stats=True)
+    Wo2, so2, _, _ = O.learn_cd_tile(R, tileP=32, order=order, l1r=l1, l2r=4.0, optTol=tol, seed=seed,
+                                     binary=True, return_stats=True, imodel=Wo1)
+    for Wn, Wo, sn, so in ((W1, Wo1, s1, so1), (W2, Wo2, s2, so2)):
+        d = abs(Wn - Wo)
+        assert Wo.nnz > 300 and (d.max() if d.nnz else 0.0) <= 3e-7
+        assert (sn == so["sweeps"]).mean() >= 0.97
