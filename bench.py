@@ -713,6 +713,8 @@ def item_space_grid(args, dev, npairs=3):
                               "kernel time",
                 "note": "round 3, tile kernel (profiles/r03/c5_grid_45pairs.txt): cold pair 157.9 s, "
                         "one-sweep pairs 38-40 s; the whole 45-pair grid: profiles/r04/"}
+    except Exception as e:   # noqa: BLE001 -- an extra must not cost the line
+        return {"error": "%s: %s" % (type(e).__name__, e)}
     finally:
         for k, v in saved.items():
             if v is not None:
