@@ -12,7 +12,7 @@ import scipy.sparse as sp
 import slim_oracle as O
 from conftest import ROOT, has_gpu
 from slim_amd import _lib
-from slim_amd.constants import SLIM_NOPTIONS, SLIM_OK
+from slim_amd.constants import SLIM_ERROR_INPUT, SLIM_NOPTIONS, SLIM_OK
 
 
 def _declared():
@@ -210,6 +210,15 @@ def test_bad_arguments_are_errors_not_crashes():
     assert lib.Py_csr_load(C.byref(h), b"/nonexistent/file") < 0
     assert not lib.SLIM_ReadModel(b"/nonexistent/file")
     lib.SLIM_FreeModel(C.byref(C.c_void_p()))  # NULL is fine
+    # models resident in HBM (slim_gpu.h): a null matrix / model is an input error, a null free a no-op
+    st = C.c_int32(12345)
+    assert not lib.SLIMGPU_LearnResident(None, None, None, None, C.byref(st)) and st.value == SLIM_ERROR_INPUT
+    assert "null matrix" in _lib.last_error()
+    st = C.c_int32(12345)
+    assert not lib.SLIMGPU_ModelFetch(None, C.byref(st)) and st.value == SLIM_ERROR_INPUT
+    assert lib.SLIMGPU_ModelFetchBegin(None) == SLIM_ERROR_INPUT and lib.SLIMGPU_ModelNnz(None) == -1
+    assert lib.SLIMGPU_ModelPredict(10, None, None, None, None) == SLIM_ERROR_INPUT
+    lib.SLIMGPU_ModelFree(C.byref(C.c_void_p()))
 
 
 @pytest.mark.skipif(has_gpu(), reason="this box has a GPU")
